@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Decode-throughput bench of the dequant-matmul hot path (BASELINE.json metric).
+
+A "step" is ONE decoded token at batch 1 = one pass over all 224 quantized linears of a
+Llama-3.1-8B-shaped model (32 layers x {q,k,v,o,gate,up,down}), every layer with its own packed
+buffers (2.8 GB working set >> the 256 MB Infinity Cache), captured once into a HIP graph and
+replayed.  Inputs are resident in HBM before the timed region.  Default workload = BASELINE.json
+configs[1]: uniform `tcomb_6_7_0.5_none_0.9` (TCQ 3.25 b/w, CombtLinearTCQ).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU; default `--parallel dp` = N independent replicas decoding N token streams
+(weak scaling, no data-path collective — how an 8B model that fits one GPU is served); `--parallel tp`
+row-shards every linear over the ranks and all-gathers the activations over RCCL/xGMI (strong scaling).
+
+Prints ONE JSON line (rank 0).  roofline: HBM-bound; achieved = algorithmic bytes per token (packed
+weights + codebooks + x + out of every linear) / measured time per token, per GPU,
+timed with HIP events on the launch stream; per-launch figures = per-token / 224.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+
+WORKLOADS = {
+    # name -> (model_key, quantizer for every linear, fused layer list or None)
+    "llama3.1-8b_tcomb_6_7": ("3_8b", "tcomb_6_7_0.5_none_0.9"),
+    "llama3.1-8b_tcq_6": ("3_8b", "tcq_6_none_0.9"),
+    "llama3.1-8b_ldlq_1_4": ("3_8b", "ldlq_1_4_none_1.0"),
+    "llama3.1-70b_tcq_6": ("3_70b", "tcq_6_none_0.9"),
+}
+LINEAR_ORDER = ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj",
+                "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"]
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="llama3.1-8b_tcomb_6_7", choices=sorted(WORKLOADS))
+    ap.add_argument("--parallel", default="dp", choices=["dp", "tp"])
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="1: every GEMV on one stream; 3: q|k|v and gate|up fork onto side streams inside the graph")
+    ap.add_argument("--layers", type=int, default=0, help="override the number of layers (0 = model's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def build_model(qp, torch, model_key, qstr, nlayers, device, shard=None):
+    """-> list over layers of list of (module, in_features); every layer has distinct buffers."""
+    li = qp.mem_op.get_layer_info(model_key)
+    layers, infos0 = [], None
+    for layer in range(nlayers):
+        mods = []
+        for j, key in enumerate(LINEAR_ORDER):
+            k, m = li[key]["in_features"], li[key]["out_features"]
+            if shard is not None:  # row shard (out_features) of this rank
+                rank, world = shard
+                m = qp.shard.shard_rows(m, world)[rank]
+            info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=layer * 16 + j, device=device)
+            mod = qp.make_linear_from_info(qstr, info).to(device)
+            mods.append((mod, k, info if layer == 0 else None))
+        layers.append(mods)
+    return layers
+
+
+def algorithmic_bytes(qp, layers, batch):
+    """Bytes every token must read/write at least once: packed weights + codebook + x (fp16) + out."""
+    total = 0
+    for mods in layers:
+        for mod, k, _ in mods:
+            for name in ("trellis", "trellis1", "trellis2", "qweight", "tlut", "lut"):
+                t = getattr(mod, name, None)
+                if t is not None:
+                    total += t.numel() * t.element_size()
+            total += batch * k * 2 + batch * mod.out_features * 4
+    return total
+
+
+def cpu_baseline(qp, layers, batch, seconds):
+    """Time the CPU oracle (kind "port": fake-dequant to fp16 W, then fp32-accumulate x @ W.T, all host
+    cores via OpenMP) on ONE layer's 7 linears of the same workload, repeated within the time budget."""
+    import numpy as np
+    from oracle import oracle
+
+    mods = layers[0]
+    host = []
+    for mod, k, info in mods:
+        m = mod.out_features
+        x = np.random.default_rng(0).standard_normal((batch, k)).astype(np.float16)
+        host.append((info, m, k, x, np.empty((m, k), dtype=np.uint16)))
+
+    def one_layer():
+        for info, m, k, x, scratch in host:
+            if "trellis1" in info:
+                oracle.cpu_tcq_linear(info["trellis1"].cpu().numpy(), info["trellis2"].cpu().numpy(),
+                                      info["tlut"].cpu().numpy(), x, m, batch, k, info["tlut_bits"], info["KV"][0],
+                                      info["KV"][1], 2, scratch)
+            elif "trellis" in info:
+                oracle.cpu_tcq_linear(info["trellis"].cpu().numpy(), None, info["tlut"].cpu().numpy(), x, m, batch, k,
+                                      info["tlut_bits"], info["KV"], 0, 0, scratch)
+            else:
+                oracle.cpu_lut_tc_linear(info["qweight"].cpu().numpy(), info["lut"].cpu().numpy(), x, m, batch, k,
+                                         info["lut_bits"], info["vec_sz"], scratch)
+
+    one_layer()  # warm-up (page faults, table init)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        one_layer()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or reps >= 50:
+            break
+    t_layer = el / reps
+    nl = len(layers)
+    return {"value": 1.0 / (t_layer * nl), "unit": "tokens/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"1 of {nl} layers (7 linears, batch {batch}) x {reps} reps = {el:.1f} s; "
+                      f"per-token time extrapolated as {nl} x per-layer time"}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path is the product; there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    import qpalette_amd as qp
+    qp._native.lib()
+
+    model_key, qstr = WORKLOADS[args.workload]
+    nlayers = args.layers or qp.mem_op.get_layer_info(model_key)["nlayers"]
+    tp = args.parallel == "tp" and world > 1
+    torch.manual_seed(1234)
+    layers = build_model(qp, torch, model_key, qstr, nlayers, device, shard=(rank, world) if tp else None)
+    n = args.batch
+    xs = {}
+    for mod, k, _ in layers[0]:
+        if k not in xs:
+            xs[k] = torch.randn(n, k, device=device).half()
+    gather = qp.shard.make_gatherer(world, device) if tp else None
+
+    main_stream = torch.cuda.Stream(device)
+    side = [torch.cuda.Stream(device) for _ in range(2)] if args.streams >= 3 else []
+
+    def token():
+        outs = []
+        for mods in layers:
+            if side:  # q | k | v  and  gate | up are independent given x: fork/join inside the graph
+                groups = [[0, 1, 2], [3], [4, 5], [6]]
+            else:
+                groups = [[0], [1], [2], [3], [4], [5], [6]]
+            for grp in groups:
+                if len(grp) > 1:
+                    ev = torch.cuda.Event()
+                    ev.record(main_stream)
+                    evs = []
+                    for j, idx in enumerate(grp):
+                        mod, k, _ = mods[idx]
+                        if j == 0:
+                            outs.append(mod._gemv(xs[k], n))
+                        else:
+                            s = side[j - 1]
+                            s.wait_event(ev)
+                            with torch.cuda.stream(s):
+                                outs.append(mod._gemv(xs[k], n))
+                                e2 = torch.cuda.Event()
+                                e2.record(s)
+                                evs.append(e2)
+                    for e2 in evs:
+                        main_stream.wait_event(e2)
+                else:
+                    mod, k, _ = mods[grp[0]]
+                    y = mod._gemv(xs[k], n)
+                    if gather is not None and grp[0] in (3, 6):  # o_proj / down_proj feed full-width consumers
+                        y = gather(y)
+                    outs.append(y)
+        return outs
+
+    graph = None
+    with torch.cuda.stream(main_stream):
+        token()  # registers ops, sizes the allocator
+        torch.cuda.synchronize()
+        if not args.no_graph and not tp:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=main_stream):
+                token()
+        run = graph.replay if graph is not None else token
+
+        def sync_all():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            run()
+        sync_all()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(main_stream)
+        for _ in range(args.steps):
+            run()
+        e1.record(main_stream)
+        sync_all()
+        wall = time.perf_counter() - t0
+        dev_s = e0.elapsed_time(e1) / 1e3
+
+    if world > 1:
+        t = torch.tensor([wall, dev_s], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, dev_s = float(t[0]), float(t[1])
+
+    tokens = args.steps * n * (1 if tp else world)
+    value = tokens / wall
+    nlaunch = sum(len(m) for m in layers)
+    abytes = algorithmic_bytes(qp, layers, n) * (world if tp else 1)  # per token
+    t_token = dev_s / args.steps
+    achieved = abytes / (world if tp else 1) / t_token / 1e9  # per GPU
+
+    out = {
+        "metric": "decode tokens/s bs=1 Llama-3.1-8B @3.25b; achieved HBM GB/s vs peak",
+        "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if tp else "weak", "vs_baseline": None, "dtype": "f16 weights x f16 activations, f32 accumulate",
+        "data": "synthetic (random packed bits, random codebooks, random activations)",
+        "config": {"workload": f"{args.workload}: {nlayers} layers x 7 quantized linears ({qstr}), batch {n}, "
+                               f"{'HIP-graph replay' if graph is not None else 'eager'}, {args.streams} stream(s)",
+                   "parallelism": (f"tp{world} row-sharded + all-gather" if tp else f"dp{world} replicas"),
+                   "launches_per_token": nlaunch},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
+                     "kernel": "tc_gemv_kernel (all launches of a token)",
+                     "algorithmic_bytes_per_launch": abytes / (world if tp else 1) / nlaunch,
+                     "avg_launch_us": t_token / nlaunch * 1e6},
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(qp, layers, n, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def load_traffic(workload):
+    """HBM bytes per launch from the rocprofv3 PMC pass committed under profiles/ (None if absent)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload)
+    except (OSError, ValueError):
+        return None
+
+
+if __name__ == "__main__":
+    main()

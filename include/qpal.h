@@ -1,0 +1,83 @@
+/*
+ * qpal.h — C-ABI of the MI355X (gfx950) dequant-matmul hot path of Q-Palette.
+ *
+ * One runtime-shaped entry point per kernel family replaces the reference's ~8k generated,
+ * shape-templated pybind functions.  All pointers are DEVICE pointers owned by the caller (the
+ * Python op layer allocates them with the torch caching allocator); the library never allocates,
+ * frees or synchronises, launches on the stream it is given (graph-capturable) and reports errors
+ * by return code instead of exit() (reference: gpuErrchk -> exit, kernels/tcq-kernels/src/inference.h:10-18).
+ *
+ * Return value: 0 = ok; < 0 = argument error (QPAL_E_*); > 0 = hipError_t of the failed launch.
+ *
+ * Data formats (bit for bit the reference's; see DESIGN.md §2 and SURVEY.md §8a):
+ *   TCQ trellis   int16  [(m/16)*(k/16)][8*KV]      lib/linear/tcq_linear.py:31-35
+ *   TCQ codebook  fp16   [2^S][2]                   lib/linear/tcq_linear.py:37-40
+ *   LUT-TC        int32  [m][bits*k/32/vec], fp16 lut [2^bits][vec]   lib/linear/vq_linear.py:15-23
+ *   LUT-SIMT      uint32 [m][bits*k/32/vec]         lib/quantizer/pack_op.py:288-335, quant_op.py:69-78
+ *   x             fp16   [n][k] row-major, 1 <= n <= 8
+ */
+#ifndef QPAL_H
+#define QPAL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QPAL_VERSION 100
+
+#define QPAL_OK 0
+#define QPAL_E_SHAPE (-1)   /* m, k, n outside the supported set (m%32, k%32, 1<=n<=8 ...) */
+#define QPAL_E_PARAM (-2)   /* S / KV / bits / vec / split combination not supported        */
+#define QPAL_E_NULL (-3)    /* required pointer is NULL                                      */
+#define QPAL_E_ALIGN (-4)   /* pointer not aligned to the format's natural alignment         */
+
+/* split modes of the TCQ family (lib/linear/comb_linear.py) */
+#define QPAL_SPLIT_NONE 0   /* QTIPLinearTCQ:  one stream c1 @ KV1                                   */
+#define QPAL_SPLIT_ROWS 1   /* CombLinearTCQ:  rows [0,m/2) from c1 @ KV1, rows [m/2,m) from c2 @ KV2 */
+#define QPAL_SPLIT_COLS 2   /* CombtLinearTCQ: cols [0,k/2) from c1 @ KV1, cols [k/2,k) from c2 @ KV2 */
+
+/* Fused trellis decode + GEMV:  out[n][m] (fp32) = sum_k W[m][k] * x[n][k].
+ * Replaces decompress_gemm_ptr / _comb_ptr / _combt_ptr, kernels/tcq-kernels/src/inference.cu:1826-1968
+ * (bindings kernels/tcq-kernels/src/qtip_torch.cu:14-279).  `out` needs no initialisation.
+ * S in {9,10,11}; KV in 2..10 per the reference's S/KV table (lib/linear/__init__.py:166-172).   */
+int qpal_tcq_gemv(float *out, const void *c1, const void *c2, const void *x, const void *tlut,
+                  int m, int n, int k, int S, int KV1, int KV2, int split, void *stream);
+
+/* Trellis decode to fp16 W[m][k] row-major (bit-exact).  Replaces decompress_ptr / _comb_ptr /
+ * _combt_ptr, kernels/tcq-kernels/src/inference.cu:1862-1891, 1970-2035.                         */
+int qpal_tcq_dequant(void *out_f16, const void *c1, const void *c2, const void *tlut,
+                     int m, int k, int S, int KV1, int KV2, int split, void *stream);
+
+/* VQ/SQ "tensor-core" packed format: fused decode + GEMV, fp32 out[n][m].  vec in {1,2};
+ * vec=1: bits 2..8 (sq_dup / sq), vec=2: bits 2..12 (vq2).
+ * Replaces decompress_gemm_ptr, kernels/vq-tensor-kernels/src/inference.cu:1112-1180.            */
+int qpal_lut_tc_gemv(float *out, const void *qweight, const void *x, const void *lut,
+                     int m, int n, int k, int bits, int vec, void *stream);
+
+/* Same format decoded to fp16 W[m][k].  Replaces decompress_ptr, vq-tensor inference.cu:1182-1226. */
+int qpal_lut_tc_dequant(void *out_f16, const void *qweight, const void *lut,
+                        int m, int k, int bits, int vec, void *stream);
+
+/* SIMT packed formats (vec=1: sq_pack_gemm.pack_gemm, kernels/sq-cuda-kernels/gemm.cu:40-85;
+ * vec in {2,4}: vq_pack_gemm_*, kernels/vq-cuda-kernels/src/gemm.cu:25-100).  fp16 out[n][m].
+ * Accumulates in fp32 (the reference accumulates in fp16) and rounds once at the end.           */
+int qpal_lut_simt_gemv(void *out_f16, const void *qweight, const void *x, const void *lut,
+                       int m, int n, int k, int bits, int vec, void *stream);
+
+int qpal_lut_simt_dequant(void *out_f16, const void *qweight, const void *lut,
+                          int m, int k, int bits, int vec, void *stream);
+
+/* Re-pack a tensor-core-format qweight into the SIMT format on the device (load-time step of
+ * VQLinearPackSIMT.gen_layer_from_info, lib/linear/vq_linear.py:175-188 ->
+ * lib/quantizer/quant_op.py:246-257).  vec in {1,2}.  dst: uint32 [m][bits*k/32/vec], zeroed by the call. */
+int qpal_tc_to_simt(void *dst_simt, const void *src_tc, int m, int k, int bits, int vec, void *stream);
+
+const char *qpal_error_string(int code);
+int qpal_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QPAL_H */

@@ -1,0 +1,28 @@
+"""qpalette_amd — MI355X (gfx950) native implementation of Q-Palette's dequant-matmul hot path.
+
+Layout:
+  csrc/            hand-written HIP kernels + the C-ABI (include/qpal.h) -> libqpal_hip.so
+  _native.py       ctypes binding of the C-ABI (fails loudly when the library is missing)
+  ops.py           ``torch.ops.ours_lib.*`` operator surface of the reference (lib/linear/__init__.py)
+  linear/          nn.Module mirror of lib/linear/{tcq,comb,vq}_linear.py
+  mem_op.py        quantizer-string grammar, Llama layer shapes, synthetic packed weights
+                   (lib/utils/mem_op.py:2-307)
+  shard.py         row-sharding of packed layers across GPUs (torch.distributed / RCCL)
+
+There is deliberately no CPU implementation here: the CPU restatement lives in /oracle and is test
+infrastructure only.
+"""
+from . import _native  # noqa: F401
+from . import ops  # noqa: F401
+from . import mem_op  # noqa: F401
+from . import shard  # noqa: F401
+from .linear import (  # noqa: F401
+    CombLinearTCQ,
+    CombtLinearTCQ,
+    QTIPLinearTCQ,
+    VQLinearPackSIMT,
+    VQLinearPackTensorCore,
+    make_linear_from_info,
+)
+
+__version__ = "0.1.0"

@@ -1,0 +1,64 @@
+"""ctypes binding of libqpal_hip.so (C-ABI: include/qpal.h).
+
+The HIP library is the product: there is no fallback.  ``lib()`` raises if it has not been built
+(``python -c 'import __graft_entry__ as g; g.build()'`` or ``make -C q-palette_amd/csrc``)."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libqpal_hip.so")
+_lib = None
+
+QPAL_SPLIT_NONE, QPAL_SPLIT_ROWS, QPAL_SPLIT_COLS = 0, 1, 2
+
+_P, _I = ctypes.c_void_p, ctypes.c_int
+_SIGNATURES = {
+    "qpal_tcq_gemv": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "qpal_tcq_dequant": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "qpal_lut_tc_gemv": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "qpal_lut_tc_dequant": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "qpal_lut_simt_gemv": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "qpal_lut_simt_dequant": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "qpal_tc_to_simt": [_P, _P, _I, _I, _I, _I, _P],
+}
+
+
+class QpalError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile every HIP translation unit for gfx950 and link libqpal_hip.so (cross-compiles on CPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j", str(min(8, os.cpu_count() or 1))]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return SO_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise QpalError(
+                f"{SO_PATH} is missing: the HIP extension is the only implementation of this path "
+                "(no CPU fallback). Build it with __graft_entry__.build() or `make -C q-palette_amd/csrc`.")
+        l = ctypes.CDLL(SO_PATH)
+        for name, args in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = _I
+        l.qpal_error_string.argtypes = [_I]
+        l.qpal_error_string.restype = ctypes.c_char_p
+        l.qpal_version.restype = _I
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().qpal_error_string(rc).decode()
+        raise QpalError(f"{what} failed: {msg} (code {rc})")
+
+
+def exported_symbols():
+    return list(_SIGNATURES) + ["qpal_error_string", "qpal_version"]

@@ -1,0 +1,15 @@
+// Launchers of the VQ/SQ (LUT) kernel instantiations.
+#pragma once
+#include "simt_kernels.h"
+#include "tc_kernels.h"
+
+namespace qpal {
+int launch_lut_tc_gemv_nb1(const TcParams &p, int bits, int vec, int grid, hipStream_t stream);
+int launch_lut_tc_gemv_nb2(const TcParams &p, int bits, int vec, int grid, hipStream_t stream);
+int launch_lut_tc_gemv_nb4(const TcParams &p, int bits, int vec, int grid, hipStream_t stream);
+int launch_lut_tc_gemv_nb8(const TcParams &p, int bits, int vec, int grid, hipStream_t stream);
+int launch_lut_tc_dequant(const TcParams &p, int bits, int vec, int grid, hipStream_t stream);
+int launch_simt_gemv(const SimtParams &p, int bits, int vec, int nb, int grid, hipStream_t stream);
+int launch_simt_dequant(const SimtParams &p, int bits, int vec, int grid, hipStream_t stream);
+int launch_tc_to_simt(uint32_t *dst, const uint32_t *src, int m, int k, int bits, int vec, hipStream_t stream);
+}  // namespace qpal

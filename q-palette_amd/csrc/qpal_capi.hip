@@ -1,0 +1,263 @@
+// C-ABI entry points (include/qpal.h): argument checks, launch geometry, dispatch.  No allocation, no
+// synchronisation, everything on the caller's stream (graph-capturable).
+#include <hip/hip_runtime.h>
+
+#include "lut_kernels_api.h"
+#include "tcq_kernels_api.h"
+
+using namespace qpal;
+
+namespace {
+
+inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+// reference's S/KV table (lib/linear/__init__.py:166-172)
+bool tcq_pair_ok(int S, int KV) {
+    if (S == 9) return KV >= 2 && KV <= 10;
+    if (S == 10) return KV >= 8 && KV <= 10;
+    if (S == 11) return KV >= 9 && KV <= 10;
+    return false;
+}
+
+bool lut_tc_ok(int bits, int vec) {
+    if (vec == 1) return bits >= 2 && bits <= 8;
+    if (vec == 2) return bits >= 2 && bits <= 12;
+    return false;
+}
+
+bool simt_ok(int bits, int vec) {
+    if (vec == 1) return bits >= 2 && bits <= 8;
+    if (vec == 2) return bits >= 3 && bits <= 12;
+    if (vec == 4) return bits >= 6 && bits <= 12;
+    return false;
+}
+
+int nb_of(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : 8; }
+
+// Launch geometry of the fused GEMV.  16 waves per workgroup, one workgroup per CU.  A supertile row
+// (32 output rows) has `st` steps; it is cut into `wpr` (waves per row, power of two <= 16) x `sk`
+// (workgroups, atomics) chunks so that the whole chip (4096 wave slots) is busy when the layer is
+// small and each wave gets a few steps when it is large.
+void gemv_geometry(int nrows, int st, int &log2_wpr, int &sk, int &nitems, int &grid) {
+    const long total = (long)nrows * st;
+    const long slots = (long)kNumCU * 16;
+    long spw = (total + slots - 1) / slots;  // steps per wave if perfectly spread
+    if (spw < 1) spw = 1;
+    if (spw > 8) spw = 8;
+    long chunks = (st + spw - 1) / spw;      // chunks per supertile row
+    if (chunks < 1) chunks = 1;
+    if (chunks <= 16) {
+        log2_wpr = 0;
+        while ((1 << log2_wpr) < chunks) log2_wpr++;
+        sk = 1;
+    } else {
+        log2_wpr = 4;
+        sk = (int)((chunks + 15) / 16);
+        if (sk > st) sk = st;
+    }
+    const int rows_per_wg = 16 >> log2_wpr;
+    nitems = ((nrows + rows_per_wg - 1) / rows_per_wg) * sk;
+    grid = nitems < kNumCU ? nitems : kNumCU;
+}
+
+int tcq_gemv_one(float *out, long ldo, const void *c1, const void *c2, const void *x, const void *tlut, int m, int n,
+                 int k, int k1, int k2, int S, int KV1, int KV2, hipStream_t stream) {
+    TcParams p{};
+    p.out = out;
+    p.ldo = ldo;
+    p.c1 = static_cast<const uint32_t *>(c1);
+    p.c2 = static_cast<const uint32_t *>(c2);
+    p.x = static_cast<const uint16_t *>(x);
+    p.tab = tlut;
+    p.n = n;
+    p.k = k;
+    p.nrows = m / 32;
+    p.nsc1 = k1 / 32;
+    p.nsc2 = k2 / 32;
+    p.st1 = (p.nsc1 + 3) / 4;
+    p.st2 = (p.nsc2 + 3) / 4;
+    p.col2 = k1;
+    int grid;
+    gemv_geometry(p.nrows, p.st1 + p.st2, p.log2_wpr, p.sk, p.nitems, grid);
+    if (p.sk > 1) {
+        for (int b = 0; b < n; b++) {
+            hipError_t e = hipMemsetAsync(out + (long)b * ldo, 0, sizeof(float) * (size_t)m, stream);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    switch (nb_of(n)) {
+        case 1: return launch_tcq_gemv_nb1(p, S, KV1, KV2, grid, stream);
+        case 2: return launch_tcq_gemv_nb2(p, S, KV1, KV2, grid, stream);
+        case 4: return launch_tcq_gemv_nb4(p, S, KV1, KV2, grid, stream);
+        default: return launch_tcq_gemv_nb8(p, S, KV1, KV2, grid, stream);
+    }
+}
+
+int tcq_check(const void *c1, const void *c2, const void *tlut, int m, int k, int S, int KV1, int KV2, int split) {
+    if (!c1 || !tlut) return QPAL_E_NULL;
+    if (split != QPAL_SPLIT_NONE && !c2) return QPAL_E_NULL;
+    if (m <= 0 || k <= 0 || m % 32 || k % 32) return QPAL_E_SHAPE;
+    if (split == QPAL_SPLIT_ROWS && (m % 64)) return QPAL_E_SHAPE;
+    if (split == QPAL_SPLIT_COLS && (k % 64)) return QPAL_E_SHAPE;
+    if (split < 0 || split > 2) return QPAL_E_PARAM;
+    if (!tcq_pair_ok(S, KV1)) return QPAL_E_PARAM;
+    if (split != QPAL_SPLIT_NONE && (!tcq_pair_ok(S, KV2) || KV2 != KV1 + 1)) return QPAL_E_PARAM;
+    if (!aligned(c1, 4) || (c2 && !aligned(c2, 4)) || !aligned(tlut, 4)) return QPAL_E_ALIGN;
+    return QPAL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qpal_tcq_gemv(float *out, const void *c1, const void *c2, const void *x, const void *tlut, int m, int n, int k,
+                  int S, int KV1, int KV2, int split, void *stream) {
+    int rc = tcq_check(c1, c2, tlut, m, k, S, KV1, KV2, split);
+    if (rc) return rc;
+    if (!out || !x) return QPAL_E_NULL;
+    if (n < 1 || n > 8) return QPAL_E_SHAPE;
+    if (!aligned(x, 8) || !aligned(out, 4) || (k % 4)) return QPAL_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (split == QPAL_SPLIT_NONE) return tcq_gemv_one(out, m, c1, nullptr, x, tlut, m, n, k, k, 0, S, KV1, 0, s);
+    if (split == QPAL_SPLIT_COLS)
+        return tcq_gemv_one(out, m, c1, c2, x, tlut, m, n, k, k / 2, k / 2, S, KV1, KV2, s);
+    // row halves: two independent single-stream problems writing the two halves of each output row
+    rc = tcq_gemv_one(out, m, c1, nullptr, x, tlut, m / 2, n, k, k, 0, S, KV1, 0, s);
+    if (rc) return rc;
+    return tcq_gemv_one(out + m / 2, m, c2, nullptr, x, tlut, m / 2, n, k, k, 0, S, KV2, 0, s);
+}
+
+int qpal_tcq_dequant(void *out_f16, const void *c1, const void *c2, const void *tlut, int m, int k, int S, int KV1,
+                     int KV2, int split, void *stream) {
+    int rc = tcq_check(c1, c2, tlut, m, k, S, KV1, KV2, split);
+    if (rc) return rc;
+    if (!out_f16) return QPAL_E_NULL;
+    if (!aligned(out_f16, 8)) return QPAL_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    auto one = [&](uint16_t *w, const void *a, const void *b, int mm, int k1, int k2, int kva, int kvb) -> int {
+        TcParams p{};
+        p.wout = w;
+        p.ldw = k;
+        p.c1 = static_cast<const uint32_t *>(a);
+        p.c2 = static_cast<const uint32_t *>(b);
+        p.tab = tlut;
+        p.nrows = mm / 32;
+        p.nsc1 = k1 / 32;
+        p.nsc2 = k2 / 32;
+        p.st1 = (p.nsc1 + 3) / 4;
+        p.st2 = (p.nsc2 + 3) / 4;
+        p.col2 = k1;
+        const int grid = p.nrows < kNumCU ? p.nrows : kNumCU;
+        return launch_tcq_dequant(p, S, kva, kvb, grid, s);
+    };
+    uint16_t *w = static_cast<uint16_t *>(out_f16);
+    if (split == QPAL_SPLIT_NONE) return one(w, c1, nullptr, m, k, 0, KV1, 0);
+    if (split == QPAL_SPLIT_COLS) return one(w, c1, c2, m, k / 2, k / 2, KV1, KV2);
+    rc = one(w, c1, nullptr, m / 2, k, 0, KV1, 0);
+    if (rc) return rc;
+    return one(w + (size_t)(m / 2) * k, c2, nullptr, m / 2, k, 0, KV2, 0);
+}
+
+int qpal_lut_tc_gemv(float *out, const void *qweight, const void *x, const void *lut, int m, int n, int k, int bits,
+                     int vec, void *stream) {
+    if (!out || !qweight || !x || !lut) return QPAL_E_NULL;
+    if (m <= 0 || k <= 0 || m % 32 || k % 32 || n < 1 || n > 8) return QPAL_E_SHAPE;
+    if (!lut_tc_ok(bits, vec) || ((long)bits * k) % (32 * vec)) return QPAL_E_PARAM;
+    if (!aligned(qweight, 4) || !aligned(x, 8) || !aligned(lut, 4) || !aligned(out, 4)) return QPAL_E_ALIGN;
+    TcParams p{};
+    p.out = out;
+    p.ldo = m;
+    p.c1 = static_cast<const uint32_t *>(qweight);
+    p.x = static_cast<const uint16_t *>(x);
+    p.tab = lut;
+    p.n = n;
+    p.k = k;
+    p.nrows = m / 32;
+    p.nsc1 = k / 32;
+    p.st1 = (p.nsc1 + 3) / 4;
+    int grid;
+    gemv_geometry(p.nrows, p.st1, p.log2_wpr, p.sk, p.nitems, grid);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (p.sk > 1) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)m * n, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    switch (nb_of(n)) {
+        case 1: return launch_lut_tc_gemv_nb1(p, bits, vec, grid, s);
+        case 2: return launch_lut_tc_gemv_nb2(p, bits, vec, grid, s);
+        case 4: return launch_lut_tc_gemv_nb4(p, bits, vec, grid, s);
+        default: return launch_lut_tc_gemv_nb8(p, bits, vec, grid, s);
+    }
+}
+
+int qpal_lut_tc_dequant(void *out_f16, const void *qweight, const void *lut, int m, int k, int bits, int vec,
+                        void *stream) {
+    if (!out_f16 || !qweight || !lut) return QPAL_E_NULL;
+    if (m <= 0 || k <= 0 || m % 32 || k % 32) return QPAL_E_SHAPE;
+    if (!lut_tc_ok(bits, vec) || ((long)bits * k) % (32 * vec)) return QPAL_E_PARAM;
+    if (!aligned(qweight, 4) || !aligned(lut, 4) || !aligned(out_f16, 8)) return QPAL_E_ALIGN;
+    TcParams p{};
+    p.wout = static_cast<uint16_t *>(out_f16);
+    p.ldw = k;
+    p.c1 = static_cast<const uint32_t *>(qweight);
+    p.tab = lut;
+    p.nrows = m / 32;
+    p.nsc1 = k / 32;
+    p.st1 = (p.nsc1 + 3) / 4;
+    const int grid = p.nrows < kNumCU ? p.nrows : kNumCU;
+    return launch_lut_tc_dequant(p, bits, vec, grid, static_cast<hipStream_t>(stream));
+}
+
+int qpal_lut_simt_gemv(void *out_f16, const void *qweight, const void *x, const void *lut, int m, int n, int k,
+                       int bits, int vec, void *stream) {
+    if (!out_f16 || !qweight || !x || !lut) return QPAL_E_NULL;
+    if (m <= 0 || k <= 0 || n < 1 || n > 8 || k % (32 * vec)) return QPAL_E_SHAPE;
+    if (!simt_ok(bits, vec)) return QPAL_E_PARAM;
+    if (!aligned(qweight, 4) || !aligned(x, 16) || !aligned(lut, 2 * vec) || !aligned(out_f16, 2) || (k % 8))
+        return QPAL_E_ALIGN;
+    SimtParams p{static_cast<uint16_t *>(out_f16), static_cast<const uint32_t *>(qweight),
+                 static_cast<const uint16_t *>(x), lut, n, m, k};
+    const int pairs = (m + 1) / 2;
+    int grid = (pairs + 15) / 16;
+    if (grid > kNumCU) grid = kNumCU;
+    return launch_simt_gemv(p, bits, vec, nb_of(n), grid, static_cast<hipStream_t>(stream));
+}
+
+int qpal_lut_simt_dequant(void *out_f16, const void *qweight, const void *lut, int m, int k, int bits, int vec,
+                          void *stream) {
+    if (!out_f16 || !qweight || !lut) return QPAL_E_NULL;
+    if (m <= 0 || k <= 0 || k % (32 * vec)) return QPAL_E_SHAPE;
+    if (!simt_ok(bits, vec)) return QPAL_E_PARAM;
+    if (!aligned(qweight, 4) || !aligned(lut, 2 * vec) || !aligned(out_f16, 16) || (k % 8)) return QPAL_E_ALIGN;
+    SimtParams p{static_cast<uint16_t *>(out_f16), static_cast<const uint32_t *>(qweight), nullptr, lut, 1, m, k};
+    const int pairs = (m + 1) / 2;
+    int grid = (pairs + 15) / 16;
+    if (grid > kNumCU) grid = kNumCU;
+    return launch_simt_dequant(p, bits, vec, grid, static_cast<hipStream_t>(stream));
+}
+
+int qpal_tc_to_simt(void *dst_simt, const void *src_tc, int m, int k, int bits, int vec, void *stream) {
+    if (!dst_simt || !src_tc) return QPAL_E_NULL;
+    if (m <= 0 || k <= 0 || m % 32 || k % 32 || k % (32 * vec)) return QPAL_E_SHAPE;
+    if (!(vec == 1 || vec == 2) || !lut_tc_ok(bits, vec) || ((long)bits * k) % (32 * vec)) return QPAL_E_PARAM;
+    if (!aligned(dst_simt, 4) || !aligned(src_tc, 4)) return QPAL_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(dst_simt, 0, (size_t)m * k / vec * bits / 8, s);
+    if (e != hipSuccess) return (int)e;
+    return launch_tc_to_simt(static_cast<uint32_t *>(dst_simt), static_cast<const uint32_t *>(src_tc), m, k, bits, vec, s);
+}
+
+const char *qpal_error_string(int code) {
+    switch (code) {
+        case QPAL_OK: return "ok";
+        case QPAL_E_SHAPE: return "unsupported shape (need m%32==0, k%32==0, 1<=n<=8)";
+        case QPAL_E_PARAM: return "unsupported quantizer parameters (S/KV/bits/vec/split)";
+        case QPAL_E_NULL: return "null pointer";
+        case QPAL_E_ALIGN: return "misaligned pointer";
+        default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "unknown qpal error";
+    }
+}
+
+int qpal_version(void) { return QPAL_VERSION; }
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) dequant-matmul kernels.  wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "qpal.h"
+
+namespace qpal {
+
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x3a __attribute__((ext_vector_type(3), aligned(4)));
+typedef uint32_t u32x2a __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+constexpr int kNumCU = 256;  // MI355X: 8 XCDs x 32 CUs
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// Streamed-once weights: KV (or `bits`) consecutive dwords per lane, 4-byte aligned, non-temporal.
+template <int NW>
+__device__ __forceinline__ void load_words_nt(const uint32_t *__restrict__ p, uint32_t (&w)[NW]) {
+    constexpr int Q = NW / 4, R = NW % 4;
+    static_for<0, Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const u32x4a v = __builtin_nontemporal_load(reinterpret_cast<const u32x4a *>(p + 4 * q));
+        w[4 * q + 0] = v.x;
+        w[4 * q + 1] = v.y;
+        w[4 * q + 2] = v.z;
+        w[4 * q + 3] = v.w;
+    });
+    if constexpr (R == 3) {
+        const u32x3a v = __builtin_nontemporal_load(reinterpret_cast<const u32x3a *>(p + 4 * Q));
+        w[4 * Q + 0] = v.x;
+        w[4 * Q + 1] = v.y;
+        w[4 * Q + 2] = v.z;
+    } else if constexpr (R == 2) {
+        const u32x2a v = __builtin_nontemporal_load(reinterpret_cast<const u32x2a *>(p + 4 * Q));
+        w[4 * Q + 0] = v.x;
+        w[4 * Q + 1] = v.y;
+    } else if constexpr (R == 1) {
+        w[4 * Q] = __builtin_nontemporal_load(p + 4 * Q);
+    }
+}
+
+// 32 bits of the lane's little-endian word array starting at compile-time bit POS (reads past the
+// end as zero: only ever the don't-care bits above a 16-bit window).
+template <int POS, int NW>
+__device__ __forceinline__ uint32_t ext32(const uint32_t (&w)[NW]) {
+    static_assert(POS >= 0, "negative bit position");
+    constexpr int i = POS >> 5, sh = POS & 31;
+    const uint32_t lo = (i < NW) ? w[i < NW ? i : 0] : 0u;
+    if constexpr (sh == 0) {
+        return lo;
+    } else {
+        const uint32_t hi = (i + 1 < NW) ? w[(i + 1 < NW) ? i + 1 : 0] : 0u;
+        return __builtin_amdgcn_alignbit(hi, lo, sh);
+    }
+}
+
+// value of lane+1 inside each row of 16 lanes (wraps 15 -> 0): one DPP move, no LDS traffic.
+__device__ __forceinline__ uint32_t row16_next(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x12F /* row_ror:15 */, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ float fdot2(uint32_t w, uint32_t x, float acc) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, w), __builtin_bit_cast(h2_t, x), acc, false);
+}
+
+__device__ __forceinline__ float wave_xor_add(float v, int mask) {
+    return v + __shfl_xor(v, mask, 64);
+}
+
+}  // namespace qpal

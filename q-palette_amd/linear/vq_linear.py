@@ -1,0 +1,108 @@
+"""VQ / non-uniform-SQ linears on the tensor-core-order packing and on the SIMT packing
+(reference: lib/linear/vq_linear.py:5-97, 99-208)."""
+import torch
+
+from .. import ops
+from ._base import PackedLinearBase, merge_row_concat, op
+
+
+def _default_device(device):
+    if device is not None:
+        return device
+    return "cuda" if torch.cuda.is_available() else "cpu"
+
+
+class _VQBase(PackedLinearBase):
+    def __init__(self, in_features, out_features, lut_bits, vec_sz, bias=False, dtype=torch.half, device=None):
+        super().__init__()
+        dev = _default_device(device)
+        self.in_features, self.out_features = in_features, out_features
+        self.lut_bits, self.vec_sz, self.dtype = lut_bits, vec_sz, dtype
+        # like the reference, buffers start with arbitrary (here: random) contents until loaded
+        self.register_buffer("qweight", torch.randint(0, 4, (out_features, lut_bits * in_features // 32 // vec_sz),
+                                                      dtype=torch.int32, device=dev))
+        self.register_buffer("lut", torch.randn((2 ** lut_bits, vec_sz), dtype=dtype, device=dev))
+        if bias:
+            self.register_buffer("bias", torch.randn((out_features,), dtype=dtype, device=dev))
+        else:
+            self.bias = None
+
+    def _info(self):
+        return {
+            "in_features": self.in_features, "out_features": self.out_features, "lut_bits": self.lut_bits,
+            "dtype": self.dtype, "vec_sz": self.vec_sz, "qweight": self.qweight.detach().cpu(),
+            "lut": self.lut.detach().cpu().half(),
+            "bias": self.bias.detach().cpu() if self.bias is not None else None,
+        }
+
+    @staticmethod
+    def merge_infos(info1, info2):
+        return merge_row_concat(info1, info2, ["in_features", "lut_bits", "vec_sz", "dtype"], ["qweight"], "lut")
+
+
+class VQLinearPackTensorCore(_VQBase):
+    """Codes stored in mma-tile order (quant_op.py:101-162); fp32 GEMV output."""
+
+    def __init__(self, in_features, out_features, lut_bits, vec_sz=2, bias=False, dtype=torch.half, device=None):
+        super().__init__(in_features, out_features, lut_bits, vec_sz, bias, dtype, device)
+        self.vq_type = f"vq{vec_sz}" if vec_sz > 1 else ("sq_dup" if lut_bits <= 4 else "sq")
+
+    def _gemv(self, x, bs):
+        m, k = self.out_features, self.in_features
+        return op(f"decompress_gemm_{m}_{bs}_{k}_{self.lut_bits}_{self.vq_type}")(self.qweight, x, self.lut)
+
+    def get_weight(self):
+        return op(f"decompress_{self.lut_bits}_{self.vq_type}")(self.qweight, self.lut, self.out_features,
+                                                                 self.in_features)
+
+    @staticmethod
+    def gen_layer_from_info(info):
+        layer = VQLinearPackTensorCore(info["in_features"], info["out_features"], info["lut_bits"], info["vec_sz"],
+                                       info["bias"] is not None, info["dtype"], device=info["qweight"].device)
+        layer.qweight.data.copy_(info["qweight"])
+        layer.lut.data.copy_(info["lut"])
+        if info["bias"] is not None:
+            layer.bias.data.copy_(info["bias"])
+        return layer
+
+
+class VQLinearPackSIMT(_VQBase):
+    """Codes stored row-major in 32-lane blocks (pack_op.py:288-335); fp16 GEMV output."""
+
+    def __init__(self, in_features, out_features, lut_bits, vec_sz=1, bias=False, dtype=torch.half, device=None):
+        super().__init__(in_features, out_features, lut_bits, vec_sz, bias, dtype, device)
+
+    def _gemv(self, x, bs):
+        x3 = x.reshape(bs, 1, self.in_features)
+        if self.vec_sz == 1:
+            y = op("sq_pack_gemm_simt")(x3, self.qweight, self.lut, self.lut_bits)
+        else:
+            y = op(f"vq_pack_gemm_simt_{bs}_{self.vec_sz}_{self.lut_bits}")(x3, self.qweight, self.lut)
+        return y.reshape(bs, self.out_features)
+
+    def get_weight(self):
+        m, k = self.out_features, self.in_features
+        if self.vec_sz == 1:
+            return op("sq_pack_dequant_simt")(self.qweight, self.lut, self.lut_bits, m, k)
+        return op(f"vq_pack_dequant_simt_{self.vec_sz}_{self.lut_bits}")(self.qweight, self.lut, m, k)
+
+    @staticmethod
+    def gen_layer_from_info(info, device=None):
+        """Layer files always hold the tensor-core packing for vec_sz <= 2; it is re-packed to the SIMT
+        layout on the device at load time (reference: vq_linear.py:175-188 -> quant_op.py:246-257)."""
+        dev = _default_device(device if device is not None else
+                              (info["qweight"].device if info["qweight"].is_cuda else None))
+        layer = VQLinearPackSIMT(info["in_features"], info["out_features"], info["lut_bits"], info["vec_sz"],
+                                 info["bias"] is not None, info["dtype"], device=dev)
+        if info["vec_sz"] <= 2:
+            if not torch.device(dev).type == "cuda":
+                raise RuntimeError("VQLinearPackSIMT needs the GPU to re-pack tensor-core-format codes (no CPU path)")
+            converted = ops.tc_to_simt(info["qweight"].to(dev), info["out_features"], info["in_features"],
+                                       info["lut_bits"], info["vec_sz"])
+            layer.qweight.data.copy_(converted)
+        else:
+            layer.qweight.data.copy_(info["qweight"])
+        layer.lut.data.copy_(info["lut"])
+        if info["bias"] is not None:
+            layer.bias.data.copy_(info["bias"])
+        return layer

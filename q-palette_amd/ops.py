@@ -1,0 +1,412 @@
+"""``torch.ops.ours_lib.*`` — the reference's operator surface (lib/linear/__init__.py) on the C-ABI.
+
+The reference registers ~12k shape-mangled ops eagerly with ``exec``; each one forwards to a pybind
+function templated on the same shape.  Here every op *name* of that grammar is registered lazily the
+first time it is looked up (``getattr(torch.ops.ours_lib, name)`` — exactly what the reference's
+modules do at every forward) and all of them forward to the runtime-shaped C-ABI entry points of
+include/qpal.h.  Same schemas, same return dtypes/shapes, ``register_fake`` for tracing, launched on
+the current stream, graph-capturable.  Dispatch key "CUDA" is HIP on PyTorch-ROCm.
+
+Name grammar (reference file:line):
+  decompress_gemm_tcq_{m}_{n}_{k}_{S}_{KV}                      lib/linear/__init__.py:176-198
+  decompress_gemm_tcq_comb|combt_{m}_{n}_{k}_{S}_{KV}_{KV+1}     :201-250
+  decompress_tcq_{S}_{KV} ; decompress_tcq_comb|combt_{S}_{KV}_{KV+1}   :260-337
+  decompress_gemm_{m}_{n}_{k}_{bits}_{sq_dup|sq|vq2}            :52-73
+  decompress_gemv_{m}_{k}_{bits}_{vtype}  (mutates out)         :75-92
+  decompress_{bits}_{vtype}                                     :94-117
+  sq_pack_gemm_simt / sq_pack_dequant_simt / sq_pack_gemm_inplace_simt   :349-378
+  vq_pack_gemm_simt_{maxm}_{vec}_{bits} ; vq_pack_dequant_simt_{vec}_{bits}   :383-420
+Unlike the reference, any 1 <= n <= 8 and any m % 32 == 0, k % 32 == 0 is accepted at run time.
+"""
+import re
+import threading
+
+import torch
+
+from . import _native as nat
+
+NS = "ours_lib"
+_lib = torch.library.Library(NS, "FRAGMENT")
+_defined = {}
+_lock = threading.RLock()
+_pending = set()  # names being registered (torch.library looks the op up again while we register it)
+
+_VTYPES = {"sq_dup": (1, 2, 4), "sq": (1, 2, 8), "vq2": (2, 2, 12)}  # vtype -> (vec, min bits, max bits)
+_TCQ_KV = {9: range(2, 11), 10: range(8, 11), 11: range(9, 11)}
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _chk(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _dev(t, name):
+    _chk(t.is_cuda, f"{name} must be a CUDA (HIP) tensor")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _x16(x, n, k):
+    _chk(x.dim() == 2 and x.shape[0] == n and x.shape[1] == k, f"x must be [{n}, {k}], got {tuple(x.shape)}")
+    return _dev(x.to(torch.float16), "x")
+
+
+def _tcq_stream_ok(c, rows, k, KV, name):
+    _chk(c.numel() * c.element_size() * 16 == KV * rows * k,
+         f"{name} holds {c.numel() * c.element_size()} bytes, expected {KV * rows * k // 16} (KV={KV}, {rows}x{k})")
+
+
+# ------------------------------------------------------------------------------------------------ TCQ
+def _tcq_gemm(m, n, k, S, KV1, KV2, split):
+    def impl(*args):
+        if split == 0:
+            c1, x, cb = args
+            c2 = None
+        else:
+            c1, c2, x, cb = args
+        c1 = _dev(c1, "compressed")
+        cb = _dev(cb, "codebook")
+        _chk(cb.dtype == torch.float16 and cb.numel() == 2 << S, f"codebook must be fp16 with {2 << S} elements")
+        xh = _x16(x, n, k)
+        if split == 0:
+            _tcq_stream_ok(c1, m, k, KV1, "compressed")
+        elif split == 1:
+            c2 = _dev(c2, "compressed2")
+            _tcq_stream_ok(c1, m // 2, k, KV1, "compressed1")
+            _tcq_stream_ok(c2, m // 2, k, KV2, "compressed2")
+        else:
+            c2 = _dev(c2, "compressed2")
+            _tcq_stream_ok(c1, m, k // 2, KV1, "compressed1")
+            _tcq_stream_ok(c2, m, k // 2, KV2, "compressed2")
+        out = torch.empty((n, m), dtype=torch.float32, device=x.device)
+        with torch.cuda.device_of(x):
+            rc = nat.lib().qpal_tcq_gemv(out.data_ptr(), c1.data_ptr(), c2.data_ptr() if c2 is not None else None,
+                                         xh.data_ptr(), cb.data_ptr(), m, n, k, S, KV1, KV2, split, _stream(x))
+        nat.check(rc, "qpal_tcq_gemv")
+        return out
+
+    def fake(*args):
+        x = args[-2]
+        return torch.empty((n, m), dtype=torch.float32, device=x.device)
+
+    return impl, fake
+
+
+def _tcq_dequant(S, KV1, KV2, split):
+    def impl(*args):
+        if split == 0:
+            c1, cb, m, k = args
+            c2 = None
+        else:
+            c1, c2, cb, m, k = args
+            c2 = _dev(c2, "compressed2")
+        c1 = _dev(c1, "compressed")
+        cb = _dev(cb, "codebook")
+        _chk(cb.dtype == torch.float16 and cb.numel() == 2 << S, f"codebook must be fp16 with {2 << S} elements")
+        if split == 0:
+            _tcq_stream_ok(c1, m, k, KV1, "compressed")
+        elif split == 1:
+            _tcq_stream_ok(c1, m // 2, k, KV1, "compressed1")
+            _tcq_stream_ok(c2, m // 2, k, KV2, "compressed2")
+        else:
+            _tcq_stream_ok(c1, m, k // 2, KV1, "compressed1")
+            _tcq_stream_ok(c2, m, k // 2, KV2, "compressed2")
+        out = torch.empty((m, k), dtype=torch.float16, device=c1.device)
+        with torch.cuda.device_of(c1):
+            rc = nat.lib().qpal_tcq_dequant(out.data_ptr(), c1.data_ptr(), c2.data_ptr() if c2 is not None else None,
+                                            cb.data_ptr(), m, k, S, KV1, KV2, split, _stream(c1))
+        nat.check(rc, "qpal_tcq_dequant")
+        return out
+
+    def fake(*args):
+        m, k = args[-2], args[-1]
+        return torch.empty((m, k), dtype=torch.float16, device=args[0].device)
+
+    return impl, fake
+
+
+# ------------------------------------------------------------------------------------------------ LUT, TC format
+def _lut_args(q, cb, m, k, bits, vec):
+    q = _dev(q, "compressed")
+    cb = _dev(cb, "codebook")
+    _chk(cb.dtype == torch.float16 and cb.numel() == vec << bits, f"codebook must be fp16 with {vec << bits} elements")
+    _chk(q.numel() * q.element_size() * 8 * vec == bits * m * k,
+         f"compressed holds {q.numel() * q.element_size()} bytes, expected {bits * m * k // (8 * vec)}")
+    return q, cb
+
+
+def _lut_gemm(m, n, k, bits, vec):
+    def impl(compressed, x, codebook):
+        q, cb = _lut_args(compressed, codebook, m, k, bits, vec)
+        xh = _x16(x, n, k)
+        out = torch.empty((n, m), dtype=torch.float32, device=x.device)
+        with torch.cuda.device_of(x):
+            rc = nat.lib().qpal_lut_tc_gemv(out.data_ptr(), q.data_ptr(), xh.data_ptr(), cb.data_ptr(), m, n, k, bits,
+                                            vec, _stream(x))
+        nat.check(rc, "qpal_lut_tc_gemv")
+        return out
+
+    def fake(compressed, x, codebook):
+        return torch.empty((n, m), dtype=torch.float32, device=x.device)
+
+    return impl, fake
+
+
+def _lut_gemv_out(m, k, bits, vec):
+    def impl(compressed, x, codebook, out):
+        q, cb = _lut_args(compressed, codebook, m, k, bits, vec)
+        xh = _x16(x, 1, k)
+        _chk(out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and out.numel() == m,
+             "out must be a contiguous fp32 CUDA tensor with m elements")
+        with torch.cuda.device_of(x):
+            rc = nat.lib().qpal_lut_tc_gemv(out.data_ptr(), q.data_ptr(), xh.data_ptr(), cb.data_ptr(), m, 1, k, bits,
+                                            vec, _stream(x))
+        nat.check(rc, "qpal_lut_tc_gemv")
+
+    def fake(compressed, x, codebook, out):
+        return None
+
+    return impl, fake
+
+
+def _lut_dequant(bits, vec):
+    def impl(compressed, codebook, m, k):
+        q, cb = _lut_args(compressed, codebook, m, k, bits, vec)
+        out = torch.empty((m, k), dtype=torch.float16, device=q.device)
+        with torch.cuda.device_of(q):
+            rc = nat.lib().qpal_lut_tc_dequant(out.data_ptr(), q.data_ptr(), cb.data_ptr(), m, k, bits, vec, _stream(q))
+        nat.check(rc, "qpal_lut_tc_dequant")
+        return out
+
+    def fake(compressed, codebook, m, k):
+        return torch.empty((m, k), dtype=torch.float16, device=compressed.device)
+
+    return impl, fake
+
+
+# ------------------------------------------------------------------------------------------------ LUT, SIMT format
+def _simt_gemm_call(x, q_weight, lut, bits, vec, output=None):
+    _chk(x.dim() == 3 and x.shape[1] == 1, "input tensor must be of shape (batch_size, 1, hidden_size)")
+    n, k = x.shape[0], x.shape[2]
+    q = _dev(q_weight, "q_weight")
+    m = q.shape[0]
+    _chk(q.dim() == 2 and q.shape[1] * 32 * vec == bits * k,
+         f"q_weight must be of shape (output_feat, {bits} * input_feat / {32 * vec})")
+    l = _dev(lut, "lut")
+    _chk(l.dtype == torch.float16 and l.numel() == vec << bits, f"lut must be fp16 with {vec << bits} elements")
+    _chk(1 <= n <= 8, "batch size must be in 1..8")
+    xh = _dev(x.to(torch.float16), "x")
+    if output is None:
+        output = torch.empty((n, 1, m), dtype=torch.float16, device=x.device)
+    else:
+        _chk(output.is_cuda and output.is_contiguous() and output.dtype == torch.float16 and output.numel() == n * m,
+             "output must be a contiguous fp16 CUDA tensor of shape (batch_size, 1, output_feat)")
+    with torch.cuda.device_of(x):
+        rc = nat.lib().qpal_lut_simt_gemv(output.data_ptr(), q.data_ptr(), xh.data_ptr(), l.data_ptr(), m, n, k, bits,
+                                          vec, _stream(x))
+    nat.check(rc, "qpal_lut_simt_gemv")
+    return output
+
+
+def _simt_dequant_call(q_weight, lut, bits, vec, m, k):
+    q = _dev(q_weight, "q_weight")
+    l = _dev(lut, "lut")
+    _chk(q.numel() * 32 * vec == bits * m * k, "q_weight size does not match (m, k, bits, vec)")
+    _chk(l.dtype == torch.float16 and l.numel() == vec << bits, f"lut must be fp16 with {vec << bits} elements")
+    out = torch.empty((m, k), dtype=torch.float16, device=q.device)
+    with torch.cuda.device_of(q):
+        rc = nat.lib().qpal_lut_simt_dequant(out.data_ptr(), q.data_ptr(), l.data_ptr(), m, k, bits, vec, _stream(q))
+    nat.check(rc, "qpal_lut_simt_dequant")
+    return out
+
+
+def tc_to_simt(qweight_tc, m, k, bits, vec):
+    """Device re-pack of a tensor-core-format qweight into the SIMT format
+    (reference: lib/quantizer/quant_op.py:246-257 convert_tensor_core_to_simt)."""
+    src = _dev(qweight_tc, "qweight")
+    dst = torch.empty((m, bits * k // 32 // vec), dtype=torch.int32, device=src.device)
+    with torch.cuda.device_of(src):
+        rc = nat.lib().qpal_tc_to_simt(dst.data_ptr(), src.data_ptr(), m, k, bits, vec, _stream(src))
+    nat.check(rc, "qpal_tc_to_simt")
+    return dst
+
+
+# ------------------------------------------------------------------------------------------------ registry
+def _register(name, schema, impl, fake):
+    _pending.add(name)
+    try:
+        _lib.define(f"{name}{schema}")
+        _lib.impl(name, impl, "CUDA")
+        torch.library.register_fake(f"{NS}::{name}")(fake)
+        _defined[name] = schema
+    finally:
+        _pending.discard(name)
+
+
+_RE = [
+    (re.compile(r"^decompress_gemm_tcq_(comb|combt)_(\d+)_(\d+)_(\d+)_(\d+)_(\d+)_(\d+)$"), "tcq_gemm2"),
+    (re.compile(r"^decompress_gemm_tcq_(\d+)_(\d+)_(\d+)_(\d+)_(\d+)$"), "tcq_gemm"),
+    (re.compile(r"^decompress_tcq_(comb|combt)_(\d+)_(\d+)_(\d+)$"), "tcq_deq2"),
+    (re.compile(r"^decompress_tcq_(\d+)_(\d+)$"), "tcq_deq"),
+    (re.compile(r"^decompress_gemm_(\d+)_(\d+)_(\d+)_(\d+)_(sq_dup|sq|vq2)$"), "lut_gemm"),
+    (re.compile(r"^decompress_gemv_(\d+)_(\d+)_(\d+)_(sq_dup|sq|vq2)$"), "lut_gemv"),
+    (re.compile(r"^decompress_(\d+)_(sq_dup|sq|vq2)$"), "lut_deq"),
+    (re.compile(r"^vq_pack_gemm_simt_(\d+)_(\d+)_(\d+)$"), "vq_simt_gemm"),
+    (re.compile(r"^vq_pack_dequant_simt_(\d+)_(\d+)$"), "vq_simt_deq"),
+]
+
+
+def _tcq_ok(S, KV):
+    return S in _TCQ_KV and KV in _TCQ_KV[S]
+
+
+def _shape_ok(m, n, k):
+    return m % 32 == 0 and k % 32 == 0 and 1 <= n <= 8
+
+
+def ensure_op(name):
+    """Register ``ours_lib::<name>`` if the name belongs to the reference's grammar. Returns True if known."""
+    if name in _defined or name in _pending:
+        return True
+    with _lock:
+        if name in _defined or name in _pending:
+            return True
+        for rx, kind in _RE:
+            mt = rx.match(name)
+            if not mt:
+                continue
+            g = mt.groups()
+            if kind == "tcq_gemm":
+                m, n, k, S, KV = map(int, g)
+                if not (_tcq_ok(S, KV) and _shape_ok(m, n, k)):
+                    return False
+                impl, fake = _tcq_gemm(m, n, k, S, KV, 0, 0)
+                _register(name, "(Tensor compressed, Tensor x, Tensor codebook) -> Tensor", impl, fake)
+            elif kind == "tcq_gemm2":
+                m, n, k, S, KV, KV2 = map(int, g[1:])
+                split = 1 if g[0] == "comb" else 2
+                if not (_tcq_ok(S, KV) and _tcq_ok(S, KV2) and KV2 == KV + 1 and _shape_ok(m, n, k)
+                        and (m % 64 == 0 if split == 1 else k % 64 == 0)):
+                    return False
+                impl, fake = _tcq_gemm(m, n, k, S, KV, KV2, split)
+                _register(name, "(Tensor compressed1, Tensor compressed2, Tensor x, Tensor codebook) -> Tensor",
+                          impl, fake)
+            elif kind == "tcq_deq":
+                S, KV = map(int, g)
+                if not _tcq_ok(S, KV):
+                    return False
+                impl, fake = _tcq_dequant(S, KV, 0, 0)
+                _register(name, "(Tensor compressed, Tensor codebook, int m, int k) -> Tensor", impl, fake)
+            elif kind == "tcq_deq2":
+                S, KV, KV2 = map(int, g[1:])
+                if not (_tcq_ok(S, KV) and _tcq_ok(S, KV2) and KV2 == KV + 1):
+                    return False
+                impl, fake = _tcq_dequant(S, KV, KV2, 1 if g[0] == "comb" else 2)
+                _register(name, "(Tensor compressed1, Tensor compressed2, Tensor codebook, int m, int k) -> Tensor",
+                          impl, fake)
+            elif kind in ("lut_gemm", "lut_gemv", "lut_deq"):
+                vec, lo, hi = _VTYPES[g[-1]]
+                if kind == "lut_gemm":
+                    m, n, k, bits = map(int, g[:-1])
+                elif kind == "lut_gemv":
+                    m, k, bits = map(int, g[:-1])
+                    n = 1
+                else:
+                    bits, m, n, k = int(g[0]), 32, 1, 64
+                if not (lo <= bits <= hi and _shape_ok(m, n, k)):
+                    return False
+                if kind == "lut_gemm":
+                    impl, fake = _lut_gemm(m, n, k, bits, vec)
+                    _register(name, "(Tensor compressed, Tensor x, Tensor codebook) -> Tensor", impl, fake)
+                elif kind == "lut_gemv":
+                    impl, fake = _lut_gemv_out(m, k, bits, vec)
+                    _register(name, "(Tensor compressed, Tensor x, Tensor codebook, Tensor(a!) out) -> ()", impl, fake)
+                else:
+                    impl, fake = _lut_dequant(bits, vec)
+                    _register(name, "(Tensor compressed, Tensor codebook, int m, int k) -> Tensor", impl, fake)
+            elif kind == "vq_simt_gemm":
+                maxm, vec, bits = map(int, g)
+                if not (vec in (2, 4) and (3 if vec == 2 else 6) <= bits <= 12 and 1 <= maxm <= 8):
+                    return False
+
+                def impl(x, q_weight, lut, _v=vec, _b=bits):
+                    return _simt_gemm_call(x, q_weight, lut, _b, _v)
+
+                def fake(x, q_weight, lut):
+                    return torch.empty((x.shape[0], 1, q_weight.shape[0]), dtype=torch.float16, device=x.device)
+
+                _register(name, "(Tensor x, Tensor q_weight, Tensor lut) -> Tensor", impl, fake)
+            elif kind == "vq_simt_deq":
+                vec, bits = map(int, g)
+                if not (vec in (2, 4) and (3 if vec == 2 else 6) <= bits <= 12):
+                    return False
+
+                def impl(q_weight, lut, m, k, _v=vec, _b=bits):
+                    return _simt_dequant_call(q_weight, lut, _b, _v, m, k)
+
+                def fake(q_weight, lut, m, k):
+                    return torch.empty((m, k), dtype=torch.float16, device=q_weight.device)
+
+                _register(name, "(Tensor q_weight, Tensor lut, int m, int k) -> Tensor", impl, fake)
+            return True
+        return False
+
+
+def _register_fixed():
+    def gemm(x, q_weight, lut, bitwidth):
+        _chk(2 <= bitwidth <= 8, "Bitwidth must be between 2 and 8.")
+        return _simt_gemm_call(x, q_weight, lut, bitwidth, 1)
+
+    def gemm_fake(x, q_weight, lut, bitwidth):
+        return torch.empty((x.shape[0], 1, q_weight.shape[0]), dtype=torch.float16, device=x.device)
+
+    _register("sq_pack_gemm_simt", "(Tensor x, Tensor q_weight, Tensor lut, int bitwidth) -> Tensor", gemm, gemm_fake)
+
+    def deq(q_weight, lut, bitwidth, m, k):
+        _chk(2 <= bitwidth <= 8, "Bitwidth must be between 2 and 8.")
+        return _simt_dequant_call(q_weight, lut, bitwidth, 1, m, k)
+
+    def deq_fake(q_weight, lut, bitwidth, m, k):
+        return torch.empty((m, k), dtype=torch.float16, device=q_weight.device)
+
+    _register("sq_pack_dequant_simt", "(Tensor q_weight, Tensor lut, int bitwidth, int m, int k) -> Tensor", deq, deq_fake)
+
+    def inplace(x, q_weight, lut, output, bitwidth):
+        _chk(2 <= bitwidth <= 8, "Bitwidth must be between 2 and 8.")
+        _simt_gemm_call(x, q_weight, lut, bitwidth, 1, output=output)
+
+    def inplace_fake(x, q_weight, lut, output, bitwidth):
+        return None
+
+    _register("sq_pack_gemm_inplace_simt",
+              "(Tensor x, Tensor q_weight, Tensor lut, Tensor(a!) output, int bitwidth) -> ()", inplace, inplace_fake)
+
+
+_register_fixed()
+
+# Lazy lookup: torch.ops.ours_lib.<name> registers the op on first access (the reference's modules
+# fetch ops with getattr(torch.ops.ours_lib, f"...") at every forward).
+_orig_ns_getattr = torch._ops._OpNamespace.__getattr__
+
+
+def _ns_getattr(self, op_name):
+    if self.name == NS and not op_name.startswith("__"):
+        ensure_op(op_name)
+    return _orig_ns_getattr(self, op_name)
+
+
+torch._ops._OpNamespace.__getattr__ = _ns_getattr
+
+
+def get_op(name):
+    """``getattr(torch.ops.ours_lib, name)`` with a clear error for names outside the grammar."""
+    if not ensure_op(name):
+        raise AttributeError(f"'{name}' is not an operator of the ours_lib grammar (see qpalette_amd/ops.py)")
+    return getattr(getattr(torch.ops, NS), name)
+
+
+def defined_ops():
+    return dict(_defined)

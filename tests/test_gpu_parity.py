@@ -1,0 +1,239 @@
+"""GPU parity tests (run on the MI355X box: ``pytest -m gpu``).  Every call goes through the
+``torch.ops.ours_lib`` operators, i.e. through the C-ABI of include/qpal.h, and is compared with the CPU
+oracle on the same inputs.
+
+Bars: decode-to-fp16 and all index arithmetic — BIT-EXACT.  Fused GEMV — fp32 accumulation vs the
+oracle's float64 sum: |err| <= 1e-5 * sum_k |w_k x_k| (k <= 28672; fp32 unit roundoff 6e-8 times a
+sqrt(k)-to-k growth factor), with fp16-output kernels (SIMT family) adding one fp16 rounding.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GEMV_RTOL_ABS = 1e-5  # times sum |w x|
+
+
+@pytest.fixture(scope="module")
+def qp():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import qpalette_amd
+    qpalette_amd._native.lib()  # fail loudly if the HIP library is missing
+    return qpalette_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+    return o
+
+
+def _g(name):
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+
+
+def _cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _bits(t):
+    return t.cpu().numpy().view(np.uint16)
+
+
+def _check_gemv(y, W, x, oracle, fp16_out=False):
+    ref, scale = oracle.gemv(W, x)
+    tol = GEMV_RTOL_ABS * scale + 1e-30
+    if fp16_out:
+        tol = tol + 2.0 ** -10 * np.abs(ref) + 2.0 ** -24
+    err = np.abs(y.astype(np.float64) - ref)
+    assert np.all(err <= tol), f"max err {err.max():.3e}, max tol-ratio {(err / tol).max():.2f}"
+
+
+TCQ_COMBOS = [(9, kv) for kv in range(2, 11)] + [(10, 8), (10, 9), (10, 10), (11, 9), (11, 10)]
+
+
+@pytest.mark.parametrize("S,KV", TCQ_COMBOS)
+def test_tcq_golden(qp, oracle, S, KV):
+    g = _g("tcq.npz")
+    m, k = int(g["m"]), int(g["k"])
+    tr, tl, W = g[f"tcq_S{S}_KV{KV}_trellis"], g[f"tcq_S{S}_KV{KV}_tlut"], g[f"tcq_S{S}_KV{KV}_W"]
+    dq = qp.ops.get_op(f"decompress_tcq_{S}_{KV}")(_cuda(tr), _cuda(tl), m, k)
+    assert np.array_equal(_bits(dq), W.view(np.uint16))
+    rng = np.random.default_rng(KV)
+    for n in (1, 3, 8):
+        x = rng.standard_normal((n, k)).astype(np.float16)
+        y = qp.ops.get_op(f"decompress_gemm_tcq_{m}_{n}_{k}_{S}_{KV}")(_cuda(tr), _cuda(x), _cuda(tl))
+        assert y.dtype == torch.float32 and tuple(y.shape) == (n, m)
+        _check_gemv(y.cpu().numpy(), W, x, oracle)
+
+
+@pytest.mark.parametrize("S,KV", [(9, 2), (9, 3), (9, 5), (9, 6), (9, 7), (9, 9), (10, 8), (10, 9), (11, 9)])
+def test_tcq_comb_combt_golden(qp, oracle, S, KV):
+    g = _g("tcq.npz")
+    m, k = int(g["m"]), int(g["k"])
+    t1, t2 = g[f"tcq_S{S}_KV{KV}_trellis"], g[f"tcq_S{S}_KV{KV + 1}_trellis"]
+    tl = g[f"tcq_S{S}_KV{KV}_tlut"]
+    W1, W2 = g[f"tcq_S{S}_KV{KV}_W"], g[f"tcq_S{S}_KV{KV + 1}_W"]
+    rng = np.random.default_rng(100 + KV)
+    # combt: column halves
+    Wt = np.concatenate([W1, W2], 1)
+    dq = qp.ops.get_op(f"decompress_tcq_combt_{S}_{KV}_{KV + 1}")(_cuda(t1), _cuda(t2), _cuda(tl), m, 2 * k)
+    assert np.array_equal(_bits(dq), Wt.view(np.uint16))
+    for n in (1, 4):
+        x = rng.standard_normal((n, 2 * k)).astype(np.float16)
+        y = qp.ops.get_op(f"decompress_gemm_tcq_combt_{m}_{n}_{2 * k}_{S}_{KV}_{KV + 1}")(
+            _cuda(t1), _cuda(t2), _cuda(x), _cuda(tl))
+        _check_gemv(y.cpu().numpy(), Wt, x, oracle)
+    # comb: row halves
+    Wr = np.concatenate([W1, W2], 0)
+    dq = qp.ops.get_op(f"decompress_tcq_comb_{S}_{KV}_{KV + 1}")(_cuda(t1), _cuda(t2), _cuda(tl), 2 * m, k)
+    assert np.array_equal(_bits(dq), Wr.view(np.uint16))
+    x = rng.standard_normal((2, k)).astype(np.float16)
+    y = qp.ops.get_op(f"decompress_gemm_tcq_comb_{2 * m}_2_{k}_{S}_{KV}_{KV + 1}")(_cuda(t1), _cuda(t2), _cuda(x), _cuda(tl))
+    _check_gemv(y.cpu().numpy(), Wr, x, oracle)
+
+
+@pytest.mark.parametrize("vec,bits", [(1, b) for b in range(2, 9)] + [(2, b) for b in range(2, 13)])
+def test_lut_tc_golden(qp, oracle, vec, bits):
+    g = _g("lut_tc.npz")
+    m, k = int(g["m"]), int(g["k"])
+    q, lut, W = g[f"tc_v{vec}_b{bits}_qweight"], g[f"tc_v{vec}_b{bits}_lut"], g[f"tc_v{vec}_b{bits}_W"]
+    vtypes = ["vq2"] if vec == 2 else (["sq_dup", "sq"] if bits <= 4 else ["sq"])
+    rng = np.random.default_rng(bits * 3 + vec)
+    for vt in vtypes:
+        dq = qp.ops.get_op(f"decompress_{bits}_{vt}")(_cuda(q), _cuda(lut), m, k)
+        assert np.array_equal(_bits(dq), W.view(np.uint16))
+        for n in (1, 2, 5):
+            x = rng.standard_normal((n, k)).astype(np.float16)
+            y = qp.ops.get_op(f"decompress_gemm_{m}_{n}_{k}_{bits}_{vt}")(_cuda(q), _cuda(x), _cuda(lut))
+            _check_gemv(y.cpu().numpy(), W, x, oracle)
+    out = torch.full((1, m), float("nan"), device="cuda")
+    x = rng.standard_normal((1, k)).astype(np.float16)
+    qp.ops.get_op(f"decompress_gemv_{m}_{k}_{bits}_{vtypes[-1]}")(_cuda(q), _cuda(x), _cuda(lut), out)
+    _check_gemv(out.cpu().numpy(), W, x, oracle)
+
+
+@pytest.mark.parametrize("vec,bits", [(1, b) for b in range(2, 9)] + [(2, b) for b in range(3, 13)]
+                         + [(4, b) for b in range(6, 13)])
+def test_simt_golden(qp, oracle, vec, bits):
+    g = _g("simt.npz")
+    m, k = int(g["m"]), int(g[f"simt_v{vec}_k"])
+    q, idx = g[f"simt_v{vec}_b{bits}_qweight"], g[f"simt_v{vec}_b{bits}_idx"]
+    rng = np.random.default_rng(bits * 5 + vec)
+    lut = rng.standard_normal((1 << bits, vec)).astype(np.float16)
+    W = lut[idx].reshape(m, k)
+    qd, ld = _cuda(q.view(np.int32)), _cuda(lut)
+    if vec == 1:
+        dq = qp.ops.get_op("sq_pack_dequant_simt")(qd, ld, bits, m, k)
+    else:
+        dq = qp.ops.get_op(f"vq_pack_dequant_simt_{vec}_{bits}")(qd, ld, m, k)
+    assert np.array_equal(_bits(dq), W.view(np.uint16))
+    for n in (1, 3, 8):
+        x = rng.standard_normal((n, 1, k)).astype(np.float16)
+        if vec == 1:
+            y = qp.ops.get_op("sq_pack_gemm_simt")(_cuda(x), qd, ld, bits)
+        else:
+            y = qp.ops.get_op(f"vq_pack_gemm_simt_{n}_{vec}_{bits}")(_cuda(x), qd, ld)
+        assert y.dtype == torch.float16 and tuple(y.shape) == (n, 1, m)
+        _check_gemv(y.float().cpu().numpy().reshape(n, m), W, x.reshape(n, k), oracle, fp16_out=True)
+
+
+@pytest.mark.parametrize("vec,bits", [(1, 3), (1, 4), (1, 8), (2, 5), (2, 8), (2, 12)])
+def test_tc_to_simt_golden(qp, vec, bits):
+    g = _g("simt.npz")
+    m, k = int(g["conv_m"]), int(g["conv_k"])
+    got = qp.ops.tc_to_simt(_cuda(g[f"conv_v{vec}_b{bits}_tc"]), m, k, bits, vec)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), g[f"conv_v{vec}_b{bits}_simt"])
+
+
+# ------------------------------------------------------------------ Llama shapes, synthetic weights
+LLAMA = [("tcomb_6_7_0.5_none_0.9", 4096, 4096), ("tcomb_6_7_0.5_none_0.9", 4096, 1024),
+         ("tcomb_6_7_0.5_none_0.9", 4096, 14336), ("tcomb_6_7_0.5_none_0.9", 14336, 4096),
+         ("tcq_6_none_0.9", 4096, 6144), ("tcq_3_none_0.9", 4096, 4096), ("tcq_8_none_0.9", 14336, 4096),
+         ("tcq_9_none_0.9", 4096, 1024), ("tcq_10_none_0.9", 4096, 2048), ("tcomb_9_10_0.5_none_0.9", 4096, 1024),
+         ("ldlq_1_4_none_1.0", 4096, 4096), ("ldlq_1_6_none_1.0", 4096, 1024), ("ldlq_2_12_none_1.0", 4096, 1024),
+         ("ldlq_2_8_none_1.0", 4096, 28672), ("ldlq_1_8_none_1.0", 4096, 4096)]
+
+
+def _oracle_weight(oracle, qstr, info, m, k):
+    if "tcomb" in qstr:
+        return oracle.tcq_dequant(info["trellis1"].numpy(), info["tlut"].numpy(), m, k, info["tlut_bits"], info["KV"][0],
+                                  c2=info["trellis2"].numpy(), KV2=info["KV"][1], split=2)
+    if "tcq" in qstr:
+        return oracle.tcq_dequant(info["trellis"].numpy(), info["tlut"].numpy(), m, k, info["tlut_bits"], info["KV"])
+    return oracle.lut_tc_dequant(info["qweight"].numpy(), info["lut"].numpy(), m, k, info["lut_bits"], info["vec_sz"])
+
+
+@pytest.mark.parametrize("qstr,k,m", LLAMA)
+def test_llama_shapes_modules(qp, oracle, qstr, k, m):
+    info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=m + k, device="cpu")
+    layer = qp.make_linear_from_info(qstr, info).cuda()
+    W = _oracle_weight(oracle, qstr, info, m, k)
+    assert np.array_equal(_bits(layer.get_weight()), W.view(np.uint16))
+    gen = torch.Generator().manual_seed(k)
+    for n in (1, 8):
+        x = torch.randn(n, k, generator=gen).half()
+        y = layer(x.cuda().float())  # fp32 in -> fp32 out keeps the kernel's fp32 result
+        assert y.dtype == torch.float32 and tuple(y.shape) == (n, m)
+        _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle)
+    # bs > 8: decode + fp16 GEMM path (what the perplexity eval exercises)
+    x = torch.randn(16, k, generator=gen).half()
+    y = layer(x.cuda()).float().cpu().numpy()
+    ref = (x.float() @ torch.from_numpy(W).float().T).numpy()
+    assert np.allclose(y, ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max())
+
+
+def test_merge_infos_is_row_concat(qp, oracle):
+    qstr, k = "tcomb_6_7_0.5_none_0.9", 4096
+    a = qp.mem_op.dummy_linear_info(k, 1024, qstr, seed=1)
+    b = qp.mem_op.dummy_linear_info(k, 1024, qstr, seed=2)
+    b["tlut"] = a["tlut"].clone()
+    merged = qp.CombtLinearTCQ.merge_infos(a, b)
+    fused = qp.CombtLinearTCQ.gen_layer_from_info(merged).cuda()
+    la, lb = qp.CombtLinearTCQ.gen_layer_from_info(a).cuda(), qp.CombtLinearTCQ.gen_layer_from_info(b).cuda()
+    x = torch.randn(1, k, generator=torch.Generator().manual_seed(3)).cuda()
+    y = fused(x)
+    assert torch.equal(y[:, :1024], la(x)) and torch.equal(y[:, 1024:], lb(x))
+
+
+def test_simt_module_loads_tensor_core_file(qp, oracle):
+    k, m = 4096, 1024
+    for qstr in ("ldlq_1_4_none_1.0", "ldlq_2_8_none_1.0"):
+        info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=7)
+        layer = qp.VQLinearPackSIMT.gen_layer_from_info(info, device="cuda")
+        W = _oracle_weight(oracle, qstr, info, m, k)
+        assert np.array_equal(_bits(layer.get_weight()), W.view(np.uint16))
+        x = torch.randn(2, k, generator=torch.Generator().manual_seed(5)).half()
+        y = layer(x.cuda())
+        _check_gemv(y.float().cpu().numpy(), W, x.numpy(), oracle, fp16_out=True)
+
+
+def test_graph_capture_and_determinism(qp):
+    qstr, k, m = "tcomb_6_7_0.5_none_0.9", 4096, 14336
+    layer = qp.make_linear_from_info(qstr, qp.mem_op.dummy_linear_info(k, m, qstr, seed=9)).cuda()
+    x = torch.randn(1, k, device="cuda")
+    eager = layer(x).clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        layer(x)
+        with torch.cuda.graph(g, stream=s):
+            y = layer(x)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, eager)
+
+
+def test_errors_are_exceptions(qp):
+    with pytest.raises(AttributeError):
+        qp.ops.get_op("decompress_gemm_tcq_4096_1_4096_9_11")  # KV outside the table
+    op = qp.ops.get_op("decompress_gemm_tcq_64_1_64_9_4")
+    with pytest.raises(RuntimeError):
+        op(torch.zeros(3, dtype=torch.int16, device="cuda"), torch.zeros(1, 64, device="cuda"),
+           torch.zeros(512, 2, dtype=torch.float16, device="cuda"))
