@@ -51,6 +51,9 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--streams", type=int, default=1,
                     help="1: every GEMV on one stream; 3: q|k|v and gate|up fork onto side streams inside the graph")
+    ap.add_argument("--launch", default="multi", choices=["single", "multi"],
+                    help="single: one launch per linear (7/layer); multi: q|k|v and gate|up (projections of one input) "
+                         "go out as one multi-job launch each (4 launches/layer, same arithmetic, same buffers)")
     ap.add_argument("--layers", type=int, default=0, help="override the number of layers (0 = model's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
@@ -167,6 +170,12 @@ def main():
     def token():
         outs = []
         for mods in layers:
+            if args.launch == "multi" and not side and gather is None:
+                outs += qp.multi_gemv([mods[0][0], mods[1][0], mods[2][0]], xs[mods[0][1]])
+                outs.append(mods[3][0]._gemv(xs[mods[3][1]], n))
+                outs += qp.multi_gemv([mods[4][0], mods[5][0]], xs[mods[4][1]])
+                outs.append(mods[6][0]._gemv(xs[mods[6][1]], n))
+                continue
             if side:  # q | k | v  and  gate | up are independent given x: fork/join inside the graph
                 groups = [[0, 1, 2], [3], [4, 5], [6]]
             else:
@@ -248,7 +257,8 @@ def main():
         "config": {"workload": f"{args.workload}: {nlayers} layers x 7 quantized linears ({qstr}), batch {n}, "
                                f"{'HIP-graph replay' if graph is not None else 'eager'}, {args.streams} stream(s)",
                    "parallelism": (f"tp{world} row-sharded + all-gather" if tp else f"dp{world} replicas"),
-                   "launches_per_token": nlaunch},
+                   "launches_per_token": (nlaunch * 4 // 7 if (args.launch == "multi" and args.streams < 3 and not tp) else nlaunch),
+                   "launch_mode": args.launch},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
                      "kernel": "tc_gemv_kernel (all launches of a token)",

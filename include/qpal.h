@@ -45,6 +45,21 @@ extern "C" {
 int qpal_tcq_gemv(float *out, const void *c1, const void *c2, const void *x, const void *tlut,
                   int m, int n, int k, int S, int KV1, int KV2, int split, void *stream);
 
+/* Several independent TCQ GEMVs of ONE codec (same S, KV1, KV2, split in {NONE, COLS}, same batch n) in a
+ * single launch: out/c1/c2/x/tlut/m/k per job.  No counterpart in the reference (it launches one kernel
+ * per linear); exists because on MI355X a launch costs ~5 us of fixed time, more than the q/k/v/o GEMVs
+ * themselves.  Intended for projections of one input (q|k|v, gate|up); njobs <= 8.                  */
+typedef struct qpal_tcq_job {
+    float *out;        /* fp32 [n][m] */
+    const void *c1;    /* stream 1 */
+    const void *c2;    /* stream 2 (split COLS) or NULL */
+    const void *x;     /* fp16 [n][k] */
+    const void *tlut;  /* fp16 [2^S][2] */
+    int m, k;
+} qpal_tcq_job;
+int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int KV1, int KV2, int split,
+                        void *stream);
+
 /* Trellis decode to fp16 W[m][k] row-major (bit-exact).  Replaces decompress_ptr / _comb_ptr /
  * _combt_ptr, kernels/tcq-kernels/src/inference.cu:1862-1891, 1970-2035.                         */
 int qpal_tcq_dequant(void *out_f16, const void *c1, const void *c2, const void *tlut,
@@ -55,6 +70,15 @@ int qpal_tcq_dequant(void *out_f16, const void *c1, const void *c2, const void *
  * Replaces decompress_gemm_ptr, kernels/vq-tensor-kernels/src/inference.cu:1112-1180.            */
 int qpal_lut_tc_gemv(float *out, const void *qweight, const void *x, const void *lut,
                      int m, int n, int k, int bits, int vec, void *stream);
+
+typedef struct qpal_lut_job {
+    float *out;           /* fp32 [n][m] */
+    const void *qweight;  /* int32 [m][bits*k/32/vec] */
+    const void *x;        /* fp16 [n][k] */
+    const void *lut;      /* fp16 [2^bits][vec] */
+    int m, k;
+} qpal_lut_job;
+int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits, int vec, void *stream);
 
 /* Same format decoded to fp16 W[m][k].  Replaces decompress_ptr, vq-tensor inference.cu:1182-1226. */
 int qpal_lut_tc_dequant(void *out_f16, const void *qweight, const void *lut,

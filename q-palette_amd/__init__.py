@@ -23,6 +23,7 @@ from .linear import (  # noqa: F401
     VQLinearPackSIMT,
     VQLinearPackTensorCore,
     make_linear_from_info,
+    multi_gemv,
 )
 
 __version__ = "0.1.0"

@@ -1,6 +1,7 @@
 // C-ABI entry points (include/qpal.h): argument checks, launch geometry, dispatch.  No allocation, no
 // synchronisation, everything on the caller's stream (graph-capturable).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "lut_kernels_api.h"
 #include "tcq_kernels_api.h"
@@ -32,37 +33,77 @@ bool simt_ok(int bits, int vec) {
     return false;
 }
 
+// reduction buffer [16 waves][n][32] fp32 + x [n][k] fp16 must fit the kernel's LDS scratch
+int x_fits_lds(int n, int k) {
+    static const int no_xlds = getenv("QPAL_NO_XLDS") != nullptr;
+    return !no_xlds && 16 * 32 * 4 * n + 2 * n * k + 64 <= kScratchBytes && (n * k) % 8 == 0;
+}
+
 int nb_of(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : 8; }
 
 // Launch geometry of the fused GEMV.  16 waves per workgroup, one workgroup per CU.  A supertile row
-// (32 output rows) has `st` steps; it is cut into `wpr` (waves per row, power of two <= 16) x `sk`
-// (workgroups, atomics) chunks so that the whole chip (4096 wave slots) is busy when the layer is
-// small and each wave gets a few steps when it is large.
-void gemv_geometry(int nrows, int st, int &log2_wpr, int &sk, int &nitems, int &grid) {
-    const long total = (long)nrows * st;
-    const long slots = (long)kNumCU * 16;
-    long spw = (total + slots - 1) / slots;  // steps per wave if perfectly spread
-    if (spw < 1) spw = 1;
-    if (spw > 8) spw = 8;
-    long chunks = (st + spw - 1) / spw;      // chunks per supertile row
-    if (chunks < 1) chunks = 1;
-    if (chunks <= 16) {
-        log2_wpr = 0;
-        while ((1 << log2_wpr) < chunks) log2_wpr++;
-        sk = 1;
-    } else {
-        log2_wpr = 4;
-        sk = (int)((chunks + 15) / 16);
-        if (sk > st) sk = st;
-    }
-    const int rows_per_wg = 16 >> log2_wpr;
-    nitems = ((nrows + rows_per_wg - 1) / rows_per_wg) * sk;
-    grid = nitems < kNumCU ? nitems : kNumCU;
+// (32 output rows) has st1 + st2 steps; it is cut into chunks (never straddling the two streams of a
+// combt layer) handled by `wpr` waves (power of two <= 16) of `sk` workgroups.  sk > 1 needs a zeroed
+// output + float atomics, i.e. one more graph node, so it is used only when a workgroup per row group
+// would leave each wave with more than kMaxStepsPerWave steps.
+constexpr int kMaxStepsPerWave = 4;
+
+// experiment knobs (perf/ scripts only): QPAL_FORCE_SK=<n>, QPAL_MAX_SPW=<n>
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
 }
 
-int tcq_gemv_one(float *out, long ldo, const void *c1, const void *c2, const void *x, const void *tlut, int m, int n,
-                 int k, int k1, int k2, int S, int KV1, int KV2, hipStream_t stream) {
-    TcParams p{};
+void gemv_geometry(int nrows, int st1, int st2, TcParams &p, int &grid) {
+    const int st = st1 + st2;
+    const long total = (long)nrows * st;
+    const long slots = (long)kNumCU * 16;
+    long spw = (total + slots - 1) / slots;  // steps per wave if the work were spread over the whole chip
+    if (spw < 1) spw = 1;
+    static const int max_spw = env_int("QPAL_MAX_SPW", kMaxStepsPerWave);
+    static const int force_sk = env_int("QPAL_FORCE_SK", 0);
+    if (spw > max_spw) spw = max_spw;
+    long chunks = (st + spw - 1) / spw;  // chunks per supertile row
+    if (st2 > 0 && chunks < 2) chunks = 2;
+    int log2_wpr = 0, sk = 1;
+    if (chunks <= 16) {
+        while ((1 << log2_wpr) < chunks) log2_wpr++;
+    } else {
+        log2_wpr = 4;
+        // one workgroup per row: waves loop over their steps; split K over workgroups only when that
+        // loop would get long AND the row count leaves CUs idle
+        const long per_wave = (st + 15) / 16;
+        if (force_sk > 0) {
+            sk = force_sk;
+        } else if (per_wave > max_spw && nrows < kNumCU) {
+            sk = (int)((per_wave + max_spw - 1) / max_spw);
+            const int cap = (int)(kNumCU / (nrows > 0 ? nrows : 1));
+            if (sk > cap) sk = cap < 1 ? 1 : cap;
+        }
+    }
+    const int nchunk = (1 << log2_wpr) * sk;
+    int nc1 = nchunk;
+    if (st2 > 0) {
+        nc1 = (int)(((long)nchunk * st1 + st / 2) / st);
+        if (nc1 < 1) nc1 = 1;
+        if (nc1 > nchunk - 1) nc1 = nchunk - 1;
+    }
+    const int rows_per_wg = 16 >> log2_wpr;
+    p.log2_wpr = log2_wpr;
+    p.sk = sk;
+    p.nc1 = nc1;
+    p.base1 = st1 / nc1;
+    p.rem1 = st1 % nc1;
+    p.base2 = st2 > 0 ? st2 / (nchunk - nc1) : 0;
+    p.rem2 = st2 > 0 ? st2 % (nchunk - nc1) : 0;
+    p.nitems = ((nrows + rows_per_wg - 1) / rows_per_wg) * sk;
+    grid = p.nitems < kNumCU ? p.nitems : kNumCU;
+}
+
+// fills one job's parameters + geometry; returns its item count through p.nitems
+void tcq_fill(TcParams &p, float *out, long ldo, const void *c1, const void *c2, const void *x, const void *tlut, int m,
+              int n, int k, int k1, int k2) {
+    p = TcParams{};
     p.out = out;
     p.ldo = ldo;
     p.c1 = static_cast<const uint32_t *>(c1);
@@ -78,19 +119,40 @@ int tcq_gemv_one(float *out, long ldo, const void *c1, const void *c2, const voi
     p.st2 = (p.nsc2 + 3) / 4;
     p.col2 = k1;
     int grid;
-    gemv_geometry(p.nrows, p.st1 + p.st2, p.log2_wpr, p.sk, p.nitems, grid);
+    gemv_geometry(p.nrows, p.st1, p.st2, p, grid);
+    p.x_lds = x_fits_lds(n, k);
+}
+
+int zero_if_split(const TcParams &p, int m, hipStream_t stream) {
     if (p.sk > 1) {
-        for (int b = 0; b < n; b++) {
-            hipError_t e = hipMemsetAsync(out + (long)b * ldo, 0, sizeof(float) * (size_t)m, stream);
+        for (int b = 0; b < p.n; b++) {
+            hipError_t e = hipMemsetAsync(p.out + (long)b * p.ldo, 0, sizeof(float) * (size_t)m, stream);
             if (e != hipSuccess) return (int)e;
         }
     }
-    switch (nb_of(n)) {
-        case 1: return launch_tcq_gemv_nb1(p, S, KV1, KV2, grid, stream);
-        case 2: return launch_tcq_gemv_nb2(p, S, KV1, KV2, grid, stream);
-        case 4: return launch_tcq_gemv_nb4(p, S, KV1, KV2, grid, stream);
-        default: return launch_tcq_gemv_nb8(p, S, KV1, KV2, grid, stream);
+    return 0;
+}
+
+void finish_multi(TcMultiParams &mp, int &grid) {
+    int total = 0;
+    for (int j = 0; j < kMaxJobs; j++) {
+        if (j < mp.njobs) total += mp.job[j].nitems;
+        mp.item_end[j] = total;
     }
+    mp.total_items = total;
+    grid = total < kNumCU ? total : kNumCU;
+}
+
+int tcq_gemv_one(float *out, long ldo, const void *c1, const void *c2, const void *x, const void *tlut, int m, int n,
+                 int k, int k1, int k2, int S, int KV1, int KV2, hipStream_t stream) {
+    TcMultiParams mp{};
+    mp.njobs = 1;
+    tcq_fill(mp.job[0], out, ldo, c1, c2, x, tlut, m, n, k, k1, k2);
+    int rc = zero_if_split(mp.job[0], m, stream);
+    if (rc) return rc;
+    int grid;
+    finish_multi(mp, grid);
+    return launch_tcq_gemv(mp, S, KV1, KV2, grid, stream);
 }
 
 int tcq_check(const void *c1, const void *c2, const void *tlut, int m, int k, int S, int KV1, int KV2, int split) {
@@ -127,6 +189,30 @@ int qpal_tcq_gemv(float *out, const void *c1, const void *c2, const void *x, con
     return tcq_gemv_one(out + m / 2, m, c2, nullptr, x, tlut, m / 2, n, k, k, 0, S, KV2, 0, s);
 }
 
+int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int KV1, int KV2, int split, void *stream) {
+    if (!jobs) return QPAL_E_NULL;
+    if (njobs < 1 || njobs > kMaxJobs) return QPAL_E_SHAPE;
+    if (split == QPAL_SPLIT_ROWS) return QPAL_E_PARAM;  // the two row halves use different codecs: one call each
+    if (n < 1 || n > 8) return QPAL_E_SHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TcMultiParams mp{};
+    mp.njobs = njobs;
+    for (int j = 0; j < njobs; j++) {
+        const qpal_tcq_job &jb = jobs[j];
+        int rc = tcq_check(jb.c1, jb.c2, jb.tlut, jb.m, jb.k, S, KV1, KV2, split);
+        if (rc) return rc;
+        if (!jb.out || !jb.x) return QPAL_E_NULL;
+        if (!aligned(jb.x, 8) || !aligned(jb.out, 4) || (jb.k % 4)) return QPAL_E_ALIGN;
+        if (split == QPAL_SPLIT_NONE) tcq_fill(mp.job[j], jb.out, jb.m, jb.c1, nullptr, jb.x, jb.tlut, jb.m, n, jb.k, jb.k, 0);
+        else tcq_fill(mp.job[j], jb.out, jb.m, jb.c1, jb.c2, jb.x, jb.tlut, jb.m, n, jb.k, jb.k / 2, jb.k / 2);
+        rc = zero_if_split(mp.job[j], jb.m, s);
+        if (rc) return rc;
+    }
+    int grid;
+    finish_multi(mp, grid);
+    return launch_tcq_gemv(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, grid, s);
+}
+
 int qpal_tcq_dequant(void *out_f16, const void *c1, const void *c2, const void *tlut, int m, int k, int S, int KV1,
                      int KV2, int split, void *stream) {
     int rc = tcq_check(c1, c2, tlut, m, k, S, KV1, KV2, split);
@@ -158,13 +244,8 @@ int qpal_tcq_dequant(void *out_f16, const void *c1, const void *c2, const void *
     return one(w + (size_t)(m / 2) * k, c2, nullptr, m / 2, k, 0, KV2, 0);
 }
 
-int qpal_lut_tc_gemv(float *out, const void *qweight, const void *x, const void *lut, int m, int n, int k, int bits,
-                     int vec, void *stream) {
-    if (!out || !qweight || !x || !lut) return QPAL_E_NULL;
-    if (m <= 0 || k <= 0 || m % 32 || k % 32 || n < 1 || n > 8) return QPAL_E_SHAPE;
-    if (!lut_tc_ok(bits, vec) || ((long)bits * k) % (32 * vec)) return QPAL_E_PARAM;
-    if (!aligned(qweight, 4) || !aligned(x, 8) || !aligned(lut, 4) || !aligned(out, 4)) return QPAL_E_ALIGN;
-    TcParams p{};
+static void lut_fill(TcParams &p, float *out, const void *qweight, const void *x, const void *lut, int m, int n, int k) {
+    p = TcParams{};
     p.out = out;
     p.ldo = m;
     p.c1 = static_cast<const uint32_t *>(qweight);
@@ -176,18 +257,42 @@ int qpal_lut_tc_gemv(float *out, const void *qweight, const void *x, const void 
     p.nsc1 = k / 32;
     p.st1 = (p.nsc1 + 3) / 4;
     int grid;
-    gemv_geometry(p.nrows, p.st1, p.log2_wpr, p.sk, p.nitems, grid);
+    gemv_geometry(p.nrows, p.st1, 0, p, grid);
+    p.x_lds = x_fits_lds(n, k);
+}
+
+static int lut_args_ok(const void *out, const void *qweight, const void *x, const void *lut, int m, int n, int k, int bits,
+                       int vec) {
+    if (!out || !qweight || !x || !lut) return QPAL_E_NULL;
+    if (m <= 0 || k <= 0 || m % 32 || k % 32 || n < 1 || n > 8) return QPAL_E_SHAPE;
+    if (!lut_tc_ok(bits, vec) || ((long)bits * k) % (32 * vec)) return QPAL_E_PARAM;
+    if (!aligned(qweight, 4) || !aligned(x, 8) || !aligned(lut, 4) || !aligned(out, 4)) return QPAL_E_ALIGN;
+    return QPAL_OK;
+}
+
+int qpal_lut_tc_gemv(float *out, const void *qweight, const void *x, const void *lut, int m, int n, int k, int bits,
+                     int vec, void *stream) {
+    qpal_lut_job job{out, qweight, x, lut, m, k};
+    return qpal_lut_tc_gemv_multi(&job, 1, n, bits, vec, stream);
+}
+
+int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits, int vec, void *stream) {
+    if (!jobs) return QPAL_E_NULL;
+    if (njobs < 1 || njobs > kMaxJobs) return QPAL_E_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (p.sk > 1) {
-        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)m * n, s);
-        if (e != hipSuccess) return (int)e;
+    TcMultiParams mp{};
+    mp.njobs = njobs;
+    for (int j = 0; j < njobs; j++) {
+        const qpal_lut_job &jb = jobs[j];
+        int rc = lut_args_ok(jb.out, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k, bits, vec);
+        if (rc) return rc;
+        lut_fill(mp.job[j], jb.out, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k);
+        rc = zero_if_split(mp.job[j], jb.m, s);
+        if (rc) return rc;
     }
-    switch (nb_of(n)) {
-        case 1: return launch_lut_tc_gemv_nb1(p, bits, vec, grid, s);
-        case 2: return launch_lut_tc_gemv_nb2(p, bits, vec, grid, s);
-        case 4: return launch_lut_tc_gemv_nb4(p, bits, vec, grid, s);
-        default: return launch_lut_tc_gemv_nb8(p, bits, vec, grid, s);
-    }
+    int grid;
+    finish_multi(mp, grid);
+    return launch_lut_tc_gemv(mp, bits, vec, grid, s);
 }
 
 int qpal_lut_tc_dequant(void *out_f16, const void *qweight, const void *lut, int m, int k, int bits, int vec,

@@ -70,7 +70,7 @@ __device__ __forceinline__ uint32_t ext32(const uint32_t (&w)[NW]) {
 
 // value of lane+1 inside each row of 16 lanes (wraps 15 -> 0): one DPP move, no LDS traffic.
 __device__ __forceinline__ uint32_t row16_next(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x12F /* row_ror:15 */, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x12F /* row_ror:15 */, 0xF, 0xF, true);
 }
 
 __device__ __forceinline__ float fdot2(uint32_t w, uint32_t x, float acc) {

@@ -18,8 +18,11 @@
 //  * Codebooks live in LDS replicated per lane of a 32-lane ds_read_b32 group (bank = lane), so the
 //    random gathers are conflict-free; for TCQ the sign flip is folded into the table (index = top
 //    S+1 bits of h).  Per 2 weights the VALU work is: alignbit, mad_u24, shift, and_or, dot2.
-//  * fp32 accumulation with v_dot2_f32_f16.  MFMA is not used at n<=8: a 16x16x32 MFMA holds the
-//    VALU issue port as long as the dot2s it would replace.
+//  * Integer/bit VALU ops and v_dot2_f32_f16 issue at HALF rate on gfx950 (~4.3 cycles per wave64
+//    instruction, measured: perf/valu_rate.hip), which makes this decode VALU-issue-bound, not HBM-bound.
+//    The multiply-accumulates therefore go to the otherwise idle matrix pipe: the 8 decoded half2 of a
+//    lane are exactly two A fragments of v_mfma_f32_16x16x32_f16; the 16 MFMA columns carry (batch row b,
+//    column half u), so batches 1..8 cost the same VALU work.  fp32 accumulation.
 #pragma once
 #include "qpal_common.h"
 
@@ -45,6 +48,24 @@ struct TcParams {
     int log2_wpr;       // waves per supertile row inside a workgroup = 1 << log2_wpr (<= 16)
     int sk;             // split-K factor across workgroups (atomics when > 1)
     int nitems;         // work items = ceil(nrows / rows_per_wg) * sk
+    int nc1;            // of the wpr*sk chunks of a supertile row, the first nc1 belong to stream 1
+    int x_lds;          // 1: stage x[n][k] in LDS (fits beside the codebook image)
+    int base1, rem1;    // stream 1: st1 = nc1*base1 + rem1 (first rem1 chunks get one more step)
+    int base2, rem2;    // stream 2: st2 = (nchunk-nc1)*base2 + rem2
+    unsigned long long *dbg;  // QPAL_STAMPS diagnostic builds only: per-wave s_memtime stamps
+};
+
+constexpr int kMaxJobs = 8;
+
+// Several independent GEMVs (same codec, same batch) run by ONE launch: persistent workgroups walk the
+// concatenated item lists of the jobs.  Cuts the per-launch fixed cost (kernel-argument fetch, codebook
+// image build, launch gap: ~5 us) where the caller has independent projections of one input (q|k|v,
+// gate|up).  item_end[j] = items of jobs 0..j.
+struct TcMultiParams {
+    int njobs;
+    int total_items;
+    int item_end[kMaxJobs];
+    TcParams job[kMaxJobs];
 };
 
 // ================================================================================================
@@ -55,10 +76,17 @@ struct TcqCodec {
     static constexpr int NW = KV;          // dwords per lane per supertile
     static constexpr int L4 = 4 * KV;      // stream bits per reference lane per tile
     static constexpr bool kNeedsNext = true;
-    // codebook image: entry e (S+1 bits: sign flag | S index bits) x C copies, copy c at dword e*C+c
-    static constexpr int LOG2C = 14 - S;   // 32 / 16 / 8 copies -> 128 KiB for every S
+    // Codebook image: entry e = top S+1 bits of the hash h (sign flag | S index bits) lives at byte
+    // e << (15-S), i.e. exactly where those bits already sit in h, replicated over the 2^(15-S) bytes of
+    // its row (16 / 8 / 4 dword copies for S = 9 / 10 / 11; 64 KiB for every S).  The gather address is
+    // then ONE v_and_or_b32: (h & mask) | 4*(lane mod copies).  Lanes l and l+16 of a 32-lane ds_read_b32
+    // group share a copy, so half of the gathers are 2-way bank conflicts: LDS has the slack, the
+    // half-rate VALU does not (perf/valu_rate.hip).
+    static constexpr int ROWSHIFT = 15 - S;            // log2(bytes per entry row)
+    static constexpr int LOG2C = ROWSHIFT - 2;         // copies per entry
     static constexpr int C = 1 << LOG2C;
-    static constexpr int LDS_DWORDS = (1 << (S + 1)) * C;
+    static constexpr int LDS_DWORDS = (1 << (S + 1)) * C;  // 16384
+    static constexpr uint32_t HMASK = ((1u << (S + 1)) - 1u) << ROWSHIFT;
 
     template <int G>
     static constexpr int baseA() { return G * L4; }
@@ -128,8 +156,7 @@ struct TcqCodec {
         const uint32_t s = window<G, I>(w, next_head);
         uint32_t h;
         asm("v_mad_u32_u24 %0, %1, %1, %1" : "=v"(h) : "v"(s));  // s*s + s: low 16 bits exact
-        const uint32_t e = __builtin_amdgcn_ubfe(h, 15 - S, S + 1);
-        const uint32_t a = (e << (LOG2C + 2)) | laneoff;
+        const uint32_t a = (h & HMASK) | laneoff;
         return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + a);
     }
 };
@@ -204,166 +231,240 @@ struct StreamView {
     int col0;              // first x column of the stream
 };
 
+#ifdef QPAL_STAMPS
+#define QPAL_STAMP(i) do { if (p.dbg && lane == 0 && gitem == (int)blockIdx.x) p.dbg[((long)blockIdx.x * 16 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QPAL_STAMP(i) do { } while (0)
+#endif
+
+constexpr int kScratchBytes = 30 * 1024;  // LDS left beside the 128 KiB codebook image: reduction buffer + x
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+// Weights of step `step` (4 supertiles).  Supertile columns past the end of the stream re-read the last
+// valid one (uniform load count; neutralised by zero activations).
 template <int NW>
 __device__ __forceinline__ void load_step_w(const StreamView &sv, int step, int lane, uint32_t (&w)[NW]) {
-    const int sc = step * 4 + (lane >> 4);
-    if (sc < sv.nsc) {
-        load_words_nt<NW>(sv.base + ((long)step * 64 + lane) * NW, w);
-    } else {
-#pragma unroll
-        for (int i = 0; i < NW; i++) w[i] = 0u;
-    }
+    int sc = step * 4 + (lane >> 4);
+    sc = sc < sv.nsc ? sc : sv.nsc - 1;
+    load_words_nt<NW>(sv.base + ((long)sc * 16 + (lane & 15)) * NW, w);
 }
 
-// x fragments of a step: xv[b][ksub*2+jh] = the 4 halves at col0 + 128*step + 32*sc + 16*ksub + 8*jh + 4*u
-// (.x feeds reference lane A's vector, .y lane B's)
-template <int NB>
-__device__ __forceinline__ void load_step_x(const StreamView &sv, const uint16_t *__restrict__ x, int k, int n,
-                                            int step, int lane, u32x2 (&xv)[NB][4]) {
+// MFMA B operand of a step.  Lane (kb = lane>>4, c = lane&15) supplies, for batch row b = c>>1 and
+// column half u = c&1, the 8 activations  x[b][col0 + 32*sc + 16*ksub + 8*jh + 4*u + 0..3], jh = 0,1
+// (order matches the A fragment: jh-major, then the reference lanes A|B, then the element of the pair).
+// XLDS: x was staged in LDS as [n][k] followed by a 64-byte zero pad (dead supertile columns of a partial
+// last step read the pad); otherwise x is read from global memory and dead lanes are zeroed by select.
+template <bool XLDS>
+__device__ __forceinline__ void load_step_x(const StreamView &sv, const uint16_t *xg, const uint16_t *xs, int k, int n,
+                                            int zero_off, int step, int lane, u32x4 (&xb)[2]) {
     const int sc = step * 4 + (lane >> 4);
     const bool live = sc < sv.nsc;
-    const long col = (long)sv.col0 + (long)sc * 32 + 4 * (lane & 1);
+    const int c = lane & 15;
+    int b = c >> 1;
+    b = b < n ? b : n - 1;
+    const int off = b * k + sv.col0 + sc * 32 + 4 * (c & 1);
+    if constexpr (XLDS) {
+        const uint16_t *row = xs + (live ? off : zero_off);
 #pragma unroll
-    for (int b = 0; b < NB; b++) {
-        const int bb = b < n ? b : n - 1;
-        const uint16_t *row = x + (long)bb * k + col;
+        for (int ksub = 0; ksub < 2; ksub++) {
+            const u32x2 lo = *reinterpret_cast<const u32x2 *>(row + 16 * ksub);
+            const u32x2 hi = *reinterpret_cast<const u32x2 *>(row + 16 * ksub + 8);
+            xb[ksub] = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+    } else {
+        const uint16_t *row = xg + (live ? off : 0);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            xv[b][q] = live ? *reinterpret_cast<const u32x2 *>(row + 8 * q) : u32x2{0u, 0u};
+        for (int ksub = 0; ksub < 2; ksub++) {
+            const u32x2 lo = *reinterpret_cast<const u32x2 *>(row + 16 * ksub);
+            const u32x2 hi = *reinterpret_cast<const u32x2 *>(row + 16 * ksub + 8);
+            xb[ksub] = live ? u32x4{lo.x, lo.y, hi.x, hi.y} : u32x4{0u, 0u, 0u, 0u};
         }
     }
 }
 
-template <class Codec, int NB>
+// One step = 8 MFMAs (16x16x32 f16): per tile group (ksub, msub) the 8 decoded half2 of a lane form the
+// A fragments of two MFMAs (jl = 0, 1: tile rows p>>1 and (p>>1)+8).  MFMA row i = lane&15 = p is the
+// VIRTUAL row (tile row p>>1, column half u = p&1); MFMA column j = 2b+u; D[i][j] is a valid partial
+// product only where the two u agree.  acc[msub*2+jl] accumulates over ksub, steps and supertiles.
+template <class Codec>
 __device__ __forceinline__ void gemv_step(const uint32_t *lut, uint32_t laneoff, const uint32_t (&w)[Codec::NW],
-                                          const u32x2 (&xv)[NB][4], float (&acc)[NB][4]) {
+                                          const u32x4 (&xb)[2], float4_t &acc0, float4_t &acc1, float4_t &acc2,
+                                          float4_t &acc3) {
     static_for<0, 4>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         constexpr int ksub = g >> 1, msub = g & 1;
         uint32_t nh = 0u;
         if constexpr (Codec::kNeedsNext) nh = row16_next(Codec::template head<g>(w));
-        static_for<0, 8>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int j = i & 3, jl = j & 1, jh = j >> 1, isB = i >> 2;
-            const uint32_t wv = Codec::template pair<g, i>(lut, laneoff, w, nh);
-#pragma unroll
-            for (int b = 0; b < NB; b++) {
-                const uint32_t xx = isB ? xv[b][ksub * 2 + jh].y : xv[b][ksub * 2 + jh].x;
-                acc[b][msub * 2 + jl] = fdot2(wv, xx, acc[b][msub * 2 + jl]);
-            }
+        const half8_t bfrag = __builtin_bit_cast(half8_t, xb[ksub]);
+        static_for<0, 2>([&](auto jc) {
+            constexpr int jl = decltype(jc)::value;
+            // fragment order (jh, isB): i = jl + 2*jh + 4*isB
+            const u32x4 a{Codec::template pair<g, jl>(lut, laneoff, w, nh),
+                          Codec::template pair<g, jl + 4>(lut, laneoff, w, nh),
+                          Codec::template pair<g, jl + 2>(lut, laneoff, w, nh),
+                          Codec::template pair<g, jl + 6>(lut, laneoff, w, nh)};
+            const half8_t afrag = __builtin_bit_cast(half8_t, a);
+            if constexpr (msub == 0 && jl == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc0, 0, 0, 0);
+            if constexpr (msub == 0 && jl == 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc1, 0, 0, 0);
+            if constexpr (msub == 1 && jl == 0) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc2, 0, 0, 0);
+            if constexpr (msub == 1 && jl == 1) acc3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc3, 0, 0, 0);
         });
     });
 }
 
-// all steps [s0, s1) of one stream for this wave, one-step-ahead register prefetch
-template <class Codec, int NB>
-__device__ __forceinline__ void gemv_stream(const uint32_t *lut, uint32_t laneoff, const StreamView &sv,
-                                            const uint16_t *__restrict__ x, int k, int n, int s0, int s1, int lane,
-                                            float (&acc)[NB][4]) {
-    constexpr int NW = Codec::NW;
-    constexpr bool XPRE = (NB <= 2) && (NW <= 10);  // prefetch x with the weights while registers allow
-    if (s0 >= s1) return;
-    uint32_t w[NW];
-    u32x2 xv[NB][4];
-    load_step_w<NW>(sv, s0, lane, w);
-    load_step_x<NB>(sv, x, k, n, s0, lane, xv);
+// steps [s0, s1) of one stream; `w` already holds step s0 (loaded before the codebook image was built)
+template <class Codec, bool XLDS>
+__device__ __forceinline__ void gemv_run(uint32_t (&w)[Codec::NW], const uint32_t *lut, uint32_t laneoff,
+                                         const StreamView &sv, const uint16_t *xg, const uint16_t *xs, int k, int n,
+                                         int zero_off, int s0, int s1, int lane, float4_t &acc0, float4_t &acc1,
+                                         float4_t &acc2, float4_t &acc3) {
     for (int s = s0; s < s1; s++) {
-        uint32_t wn[NW];
-        u32x2 xn[NB][4];
-        const bool more = s + 1 < s1;
-        if (more) {
-            load_step_w<NW>(sv, s + 1, lane, wn);
-            if constexpr (XPRE) load_step_x<NB>(sv, x, k, n, s + 1, lane, xn);
-        }
-        gemv_step<Codec, NB>(lut, laneoff, w, xv, acc);
-        if (more) {
+        uint32_t wn[Codec::NW];
+        const int sn = s + 1 < s1 ? s + 1 : s;  // last iteration re-reads its own step (L1 hit, unused)
+        load_step_w<Codec::NW>(sv, sn, lane, wn);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's decode (hipcc sinks it otherwise)
+        u32x4 xb[2];
+        load_step_x<XLDS>(sv, xg, xs, k, n, zero_off, s, lane, xb);
+        gemv_step<Codec>(lut, laneoff, w, xb, acc0, acc1, acc2, acc3);
 #pragma unroll
-            for (int i = 0; i < NW; i++) w[i] = wn[i];
-            if constexpr (XPRE) {
-#pragma unroll
-                for (int b = 0; b < NB; b++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++) xv[b][q] = xn[b][q];
-            } else {
-                load_step_x<NB>(sv, x, k, n, s + 1, lane, xv);
-            }
-        }
+        for (int i = 0; i < Codec::NW; i++) w[i] = wn[i];
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused decode + GEMV.  1024 threads (16 waves, 4 per SIMD), one workgroup per CU (LDS-bound).
-// C2 == void: single stream.  Otherwise combt (columns [0,col2) from c1 via C1, the rest from c2 via C2);
-// both codecs share one codebook image.
-template <class C1, class C2, int NB>
-__global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcParams p) {
+// Fused decode + GEMV, 1 <= n <= 8.  1024 threads (16 waves, 4 per SIMD), one workgroup per CU
+// (LDS-bound).  C2 == void: single stream.  Otherwise combt (columns [0,col2) from c1 via C1, the rest
+// from c2 via C2); both codecs share one codebook image.  A wave's chunk of steps never straddles the two
+// streams.  When they fit beside the codebook image the activations are staged once per workgroup in LDS.
+// All index arithmetic is shift/compare: the host passes the chunk partition (base/rem) precomputed.
+template <class C1, class C2>
+__global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
+    constexpr bool TWO = !std::is_void_v<C2>;
+    using CB = std::conditional_t<TWO, C2, C1>;
     __shared__ __attribute__((aligned(16))) uint32_t lut[C1::LDS_DWORDS];
-    __shared__ float red[16][NB][32];
+    __shared__ __attribute__((aligned(16))) unsigned char scratch[kScratchBytes];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t laneoff = (uint32_t)(lane & (C1::C - 1)) << 2;
 
-    C1::build(lut, p.tab, tid, 1024);
-    __syncthreads();
+    union {
+        uint32_t a[C1::NW];
+        uint32_t b[CB::NW];
+    } w;
+    const void *cur_tab = nullptr;      // codebook whose image is in LDS
+    const uint16_t *cur_x = nullptr;    // activations staged in LDS
+    int cur_j = -1;
+    TcParams p = mp.job[0];
+    for (int gitem = blockIdx.x; gitem < mp.total_items; gitem += gridDim.x) {
+        int j = 0;
+        while (gitem >= mp.item_end[j]) j++;
+        if (j != cur_j) {
+            p = mp.job[j];
+            cur_j = j;
+        }
+        const int item = gitem - (j > 0 ? mp.item_end[j - 1] : 0);
+        float *red = reinterpret_cast<float *>(scratch);                           // [16][n][32]
+        uint16_t *xs = reinterpret_cast<uint16_t *>(scratch + 16 * 32 * 4 * p.n);  // [n][k] + 32 zero halves
+        const int wpr = 1 << p.log2_wpr;
+        const int rloc = wave >> p.log2_wpr;  // supertile row inside the workgroup's row group
+        const int wr = wave & (wpr - 1);      // this wave's K-chunk inside the row
+        const int log2_rpw = 4 - p.log2_wpr;  // log2(rows per workgroup)
+        const int zero_off = p.n * p.k;
+        QPAL_STAMP(0);
 
-    const int wpr = 1 << p.log2_wpr;
-    const int rloc = wave >> p.log2_wpr;  // supertile row inside the workgroup's row group
-    const int wr = wave & (wpr - 1);      // this wave's K-chunk inside the row
-    const int rows_per_wg = 16 >> p.log2_wpr;
-    const int st = p.st1 + p.st2;
-    const int nchunk = wpr * p.sk;
+        int rg = item, ks = 0;
+        if (p.sk > 1) {
+            rg = item / p.sk;
+            ks = item - rg * p.sk;
+        }
+        const int sr = (rg << log2_rpw) + rloc;
+        const bool live = sr < p.nrows;
+        const int c = ks * wpr + wr;
+        // chunk c -> (stream, [s0, s1)): chunk j of a stream covers base steps, the first rem chunks one more
+        const bool on2 = TWO && c >= p.nc1;
+        const int cc = on2 ? c - p.nc1 : c;
+        const int base = on2 ? p.base2 : p.base1, rem = on2 ? p.rem2 : p.rem1;
+        int s0 = cc * base + (cc < rem ? cc : rem);
+        int s1 = s0 + base + (cc < rem ? 1 : 0);
+        if (!live) s0 = s1 = 0;
+        const StreamView sv1{p.c1 + (long)(live ? sr : 0) * p.nsc1 * 16 * C1::NW, p.nsc1, 0};
+        const StreamView sv2{TWO ? p.c2 + (long)(live ? sr : 0) * p.nsc2 * 16 * CB::NW : p.c1, TWO ? p.nsc2 : p.nsc1,
+                             p.col2};
+        float4_t acc0{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
 
-    for (int item = blockIdx.x; item < p.nitems; item += gridDim.x) {
-        const int rg = item / p.sk, ks = item - rg * p.sk;
-        const int sr = rg * rows_per_wg + rloc;
-        float acc[NB][4];
-#pragma unroll
-        for (int b = 0; b < NB; b++)
-#pragma unroll
-            for (int a = 0; a < 4; a++) acc[b][a] = 0.f;
-
-        if (sr < p.nrows) {
-            const int c = ks * wpr + wr;
-            const int s0 = (int)(((long)st * c) / nchunk), s1 = (int)(((long)st * (c + 1)) / nchunk);
-            {
-                const StreamView sv{p.c1 + (long)sr * p.nsc1 * 16 * C1::NW, p.nsc1, 0};
-                gemv_stream<C1, NB>(lut, laneoff, sv, p.x, p.k, p.n, s0, s1 < p.st1 ? s1 : p.st1, lane, acc);
+        // first step's weights are in flight while x and the codebook image are (re)staged
+        if (on2) load_step_w<CB::NW>(sv2, s0, lane, w.b);
+        else load_step_w<C1::NW>(sv1, s0, lane, w.a);
+        QPAL_STAMP(1);
+        if (p.tab != cur_tab || (p.x_lds && p.x != cur_x)) {  // workgroup-uniform
+            if (p.x_lds && p.x != cur_x) {
+                const int total = p.n * p.k;  // multiple of 8 halves
+                for (int i = tid * 8; i < total + 32; i += 1024 * 8) {
+                    u32x4 v{0u, 0u, 0u, 0u};
+                    if (i < total) v = *reinterpret_cast<const u32x4 *>(p.x + i);
+                    *reinterpret_cast<u32x4 *>(xs + i) = v;
+                }
+                cur_x = p.x;
             }
-            if constexpr (!std::is_void_v<C2>) {
-                const StreamView sv{p.c2 + (long)sr * p.nsc2 * 16 * C2::NW, p.nsc2, p.col2};
-                gemv_stream<C2, NB>(lut, laneoff, sv, p.x, p.k, p.n, (s0 > p.st1 ? s0 : p.st1) - p.st1, s1 - p.st1,
-                                    lane, acc);
+            if (p.tab != cur_tab) {
+                C1::build(lut, p.tab, tid, 1024);
+                cur_tab = p.tab;
+            }
+            QPAL_STAMP(2);
+            __syncthreads();
+        }
+        QPAL_STAMP(3);
+        if (p.x_lds) {
+            if (on2) gemv_run<CB, true>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc0, acc1, acc2, acc3);
+            else gemv_run<C1, true>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc0, acc1, acc2, acc3);
+        } else {
+            if (on2) gemv_run<CB, false>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc0, acc1, acc2, acc3);
+            else gemv_run<C1, false>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc0, acc1, acc2, acc3);
+        }
+        QPAL_STAMP(4);
+
+        // lane (q = lane>>4, c = lane&15 = 2b+u), register r of acc[msub*2+jl] = D[4q+r][c]; valid where
+        // r&1 == u.  On even lanes (u = 0): own r = 0 / 2 plus the odd neighbour's r = 1 / 3 are the two
+        // column halves of tile rows 2q and 2q+1.  (Odd lanes compute garbage that is never stored.)
+        {
+            const int q = lane >> 4, cidx = lane & 15, b = cidx >> 1;
+            const bool writer = (cidx & 1) == 0 && b < p.n;
+            float *dst = red + ((wave * p.n + b) * 32) + 2 * q;
+            const float a00 = acc0[0] + __shfl_xor(acc0[1], 1, 64), a01 = acc0[2] + __shfl_xor(acc0[3], 1, 64);
+            const float a10 = acc1[0] + __shfl_xor(acc1[1], 1, 64), a11 = acc1[2] + __shfl_xor(acc1[3], 1, 64);
+            const float a20 = acc2[0] + __shfl_xor(acc2[1], 1, 64), a21 = acc2[2] + __shfl_xor(acc2[3], 1, 64);
+            const float a30 = acc3[0] + __shfl_xor(acc3[1], 1, 64), a31 = acc3[2] + __shfl_xor(acc3[3], 1, 64);
+            if (writer) {  // rows 16*msub + 8*jl + 2q + {0,1}
+                dst[0] = a00;
+                dst[1] = a01;
+                dst[8] = a10;
+                dst[9] = a11;
+                dst[16] = a20;
+                dst[17] = a21;
+                dst[24] = a30;
+                dst[25] = a31;
             }
         }
-        // lanes {p, p^1} x the 4 DPP rows hold partials of the same 4 output rows
-#pragma unroll
-        for (int b = 0; b < NB; b++)
-#pragma unroll
-            for (int a = 0; a < 4; a++) {
-                float v = acc[b][a];
-                v = wave_xor_add(v, 1);
-                v = wave_xor_add(v, 16);
-                v = wave_xor_add(v, 32);
-                if (lane < 16 && (lane & 1) == 0) red[wave][b][(lane >> 1) + 8 * (a & 1) + 16 * (a >> 1)] = v;
-            }
+        QPAL_STAMP(5);
         __syncthreads();
-        if (tid < rows_per_wg * 32) {
-            const int rl = tid >> 5, r = tid & 31;
-            const int srow = rg * rows_per_wg + rl;
+        QPAL_STAMP(6);
+        if (tid < (32 << log2_rpw)) {
+            const int r = tid & 31, rl = tid >> 5;
+            const int srow = (rg << log2_rpw) + rl;
             if (srow < p.nrows) {
-#pragma unroll
-                for (int b = 0; b < NB; b++) {
-                    if (b < p.n) {
-                        float v = 0.f;
-                        for (int q = 0; q < wpr; q++) v += red[rl * wpr + q][b][r];
-                        float *dst = p.out + (long)b * p.ldo + (long)srow * 32 + r;
-                        if (p.sk == 1) *dst = v;
-                        else atomicAdd(dst, v);
-                    }
+                for (int b = 0; b < p.n; b++) {
+                    float v = 0.f;
+                    for (int qq = 0; qq < wpr; qq++) v += red[(((rl << p.log2_wpr) + qq) * p.n + b) * 32 + r];
+                    float *dst = p.out + (long)b * p.ldo + (long)srow * 32 + r;
+                    if (p.sk == 1) *dst = v;
+                    else atomicAdd(dst, v);
                 }
             }
         }
+        QPAL_STAMP(7);
         __syncthreads();
     }
 }

@@ -22,5 +22,30 @@ def make_linear_from_info(quantizer_str, linear_info, use_simt=False):
     return linear_class_for(quantizer_str, use_simt).gen_layer_from_info(linear_info)
 
 
-__all__ = ["QTIPLinearTCQ", "CombLinearTCQ", "CombtLinearTCQ", "VQLinearPackTensorCore", "VQLinearPackSIMT",
+def multi_gemv(layers, x):
+    """y_i = layers[i](x) for several quantized linears that share the input, batch <= 8.  Layers of one
+    kind and codec (e.g. q|k|v or gate|up of one block under a single-scheme quantizer) go out as ONE
+    kernel launch; anything else falls back to one launch per layer.  Returns fp32 [n, m_i] tensors."""
+    from .. import ops
+
+    x2 = x.reshape(-1, layers[0].in_features)
+    n = x2.shape[0]
+    first = layers[0]
+    same_kind = all(type(l) is type(first) and l.in_features == first.in_features for l in layers)
+    if n <= 8 and same_kind and len(layers) <= 8:
+        if isinstance(first, QTIPLinearTCQ) and all((l.KV, l.tlut_bits) == (first.KV, first.tlut_bits) for l in layers):
+            return ops.tcq_gemv_multi([(l.trellis, None, l.tlut, l.out_features) for l in layers], x2,
+                                      first.tlut_bits, first.KV)
+        if (isinstance(first, CombtLinearTCQ) and all(l.use_comb_kernel and (l.KV, l.tlut_bits) ==
+                                                      (first.KV, first.tlut_bits) for l in layers)):
+            return ops.tcq_gemv_multi([(l.trellis1, l.trellis2, l.tlut, l.out_features) for l in layers], x2,
+                                      first.tlut_bits, first.KV[0], first.KV[1], split=2)
+        if (isinstance(first, VQLinearPackTensorCore) and
+                all((l.lut_bits, l.vec_sz) == (first.lut_bits, first.vec_sz) for l in layers)):
+            return ops.lut_tc_gemv_multi([(l.qweight, l.lut, l.out_features) for l in layers], x2, first.lut_bits,
+                                         first.vec_sz)
+    return [l._gemv(x2, n) if n <= 8 else l(x2) for l in layers]
+
+
+__all__ = ["multi_gemv","QTIPLinearTCQ", "CombLinearTCQ", "CombtLinearTCQ", "VQLinearPackTensorCore", "VQLinearPackSIMT",
            "linear_class_for", "make_linear_from_info"]

@@ -223,6 +223,56 @@ def _simt_dequant_call(q_weight, lut, bits, vec, m, k):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ multi-job launches
+def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0):
+    """Several TCQ GEMVs of one codec and one input in ONE launch (C-ABI qpal_tcq_gemv_multi).
+    streams: list of (c1, c2_or_None, tlut, m); x: [n, k].  Returns the list of fp32 [n, m] outputs."""
+    n, k = x.shape
+    _chk(1 <= n <= 8, "batch size must be in 1..8")
+    xh = _dev(x.to(torch.float16), "x")
+    jobs = (nat.TcqJob * len(streams))()
+    outs, keep = [], [xh]
+    for j, (c1, c2, tlut, m) in enumerate(streams):
+        c1 = _dev(c1, "compressed1")
+        tl = _dev(tlut, "codebook")
+        _chk(tl.dtype == torch.float16 and tl.numel() == 2 << S, f"codebook must be fp16 with {2 << S} elements")
+        if split == 0:
+            _tcq_stream_ok(c1, m, k, KV1, "compressed")
+        else:
+            c2 = _dev(c2, "compressed2")
+            _tcq_stream_ok(c1, m, k // 2, KV1, "compressed1")
+            _tcq_stream_ok(c2, m, k // 2, KV2, "compressed2")
+        out = torch.empty((n, m), dtype=torch.float32, device=x.device)
+        jobs[j] = nat.TcqJob(out.data_ptr(), c1.data_ptr(), c2.data_ptr() if c2 is not None else None,
+                             xh.data_ptr(), tl.data_ptr(), m, k)
+        outs.append(out)
+        keep += [c1, c2, tl]
+    with torch.cuda.device_of(x):
+        rc = nat.lib().qpal_tcq_gemv_multi(jobs, len(streams), n, S, KV1, KV2, split, _stream(x))
+    nat.check(rc, "qpal_tcq_gemv_multi")
+    return outs
+
+
+def lut_tc_gemv_multi(layers, x, bits, vec):
+    """Several VQ/SQ (tensor-core packing) GEMVs of one codec and one input in ONE launch.
+    layers: list of (qweight, lut, m); x: [n, k]."""
+    n, k = x.shape
+    _chk(1 <= n <= 8, "batch size must be in 1..8")
+    xh = _dev(x.to(torch.float16), "x")
+    jobs = (nat.LutJob * len(layers))()
+    outs, keep = [], [xh]
+    for j, (q, lut, m) in enumerate(layers):
+        q, cb = _lut_args(q, lut, m, k, bits, vec)
+        out = torch.empty((n, m), dtype=torch.float32, device=x.device)
+        jobs[j] = nat.LutJob(out.data_ptr(), q.data_ptr(), xh.data_ptr(), cb.data_ptr(), m, k)
+        outs.append(out)
+        keep += [q, cb]
+    with torch.cuda.device_of(x):
+        rc = nat.lib().qpal_lut_tc_gemv_multi(jobs, len(layers), n, bits, vec, _stream(x))
+    nat.check(rc, "qpal_lut_tc_gemv_multi")
+    return outs
+
+
 def tc_to_simt(qweight_tc, m, k, bits, vec):
     """Device re-pack of a tensor-core-format qweight into the SIMT format
     (reference: lib/quantizer/quant_op.py:246-257 convert_tensor_core_to_simt)."""

@@ -237,3 +237,17 @@ def test_errors_are_exceptions(qp):
     with pytest.raises(RuntimeError):
         op(torch.zeros(3, dtype=torch.int16, device="cuda"), torch.zeros(1, 64, device="cuda"),
            torch.zeros(512, 2, dtype=torch.float16, device="cuda"))
+
+
+def test_multi_job_launch_equals_single_launches(qp):
+    """q|k|v and gate|up as one multi-job launch give bit-identical results to one launch per linear."""
+    k = 4096
+    for qstr, ms in (("tcomb_6_7_0.5_none_0.9", [4096, 1024, 1024]), ("tcq_6_none_0.9", [14336, 14336]),
+                     ("ldlq_2_8_none_1.0", [1024, 4096]), ("tcq_10_none_0.9", [1024, 2048, 512])):
+        layers = [qp.make_linear_from_info(qstr, qp.mem_op.dummy_linear_info(k, m, qstr, seed=m + i)).cuda()
+                  for i, m in enumerate(ms)]
+        for n in (1, 3):
+            x = torch.randn(n, k, generator=torch.Generator().manual_seed(n)).cuda()
+            ys = qp.multi_gemv(layers, x)
+            for layer, y in zip(layers, ys):
+                assert torch.equal(y, layer._gemv(x, n))
