@@ -59,9 +59,9 @@ def make_gatherer(world, device=None, group=None):
 
     def gather(y):
         n, ml = y.shape
-        buf = torch.empty((world, n, ml), dtype=y.dtype, device=y.device)
+        buf = torch.empty((world * n, ml), dtype=y.dtype, device=y.device)  # rank-major concatenation
         dist.all_gather_into_tensor(buf, y.contiguous(), group=group)
-        return buf.permute(1, 0, 2).reshape(n, world * ml)
+        return buf.view(world, n, ml).permute(1, 0, 2).reshape(n, world * ml)
 
     return gather
 

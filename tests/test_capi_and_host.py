@@ -1,0 +1,165 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/qpal.h declares (no compute
+calls without a GPU), and the host-side mirror of the reference interface behaves (op-name grammar, fake
+tensors, quantizer strings, synthetic layer shapes, layer fusion, sharding)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import qpalette_amd as qp
+from oracle import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "qpal.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qpal_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = _header_symbols()
+    assert {"qpal_tcq_gemv", "qpal_tcq_gemv_multi", "qpal_tcq_dequant", "qpal_lut_tc_gemv", "qpal_lut_tc_gemv_multi",
+            "qpal_lut_tc_dequant", "qpal_lut_simt_gemv", "qpal_lut_simt_dequant", "qpal_tc_to_simt",
+            "qpal_error_string", "qpal_version"} <= set(syms)
+    lib = qp._native.lib()
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/qpal.h but not exported"
+    assert set(qp._native.exported_symbols()) == set(syms)
+    assert lib.qpal_version() >= 100
+    assert lib.qpal_error_string(-1).decode().startswith("unsupported shape")
+
+
+def test_argument_errors_are_return_codes_not_exits():
+    lib = qp._native.lib()
+    # null pointers / bad shapes are rejected before anything touches a device
+    assert lib.qpal_tcq_gemv(None, None, None, None, None, 4096, 1, 4096, 9, 6, 0, 0, None) == -3
+    assert lib.qpal_lut_tc_dequant(None, None, None, 64, 64, 4, 1, None) == -3
+    buf = np.zeros(1 << 16, dtype=np.uint8)
+    p = buf.ctypes.data
+    assert lib.qpal_tcq_gemv(p, p, None, p, p, 4100, 1, 4096, 9, 6, 0, 0, None) == -1   # m % 32
+    assert lib.qpal_tcq_gemv(p, p, None, p, p, 4096, 9, 4096, 9, 6, 0, 0, None) == -1   # n > 8
+    assert lib.qpal_tcq_gemv(p, p, None, p, p, 4096, 1, 4096, 9, 11, 0, 0, None) == -2  # KV outside the table
+    assert lib.qpal_tcq_gemv(p, p, p, p, p, 4096, 1, 4096, 9, 6, 8, 2, None) == -2      # KV2 != KV1 + 1
+    assert lib.qpal_lut_tc_gemv(p, p, p, p, 4096, 1, 4096, 9, 1, None) == -2            # sq has bits <= 8
+    assert lib.qpal_lut_simt_gemv(p, p, p, p, 64, 1, 4096, 5, 4, None) == -2            # vec 4 needs bits >= 6
+
+
+def test_op_name_grammar():
+    good = ["decompress_gemm_tcq_4096_1_4096_9_6", "decompress_gemm_tcq_1024_7_4096_9_10",
+            "decompress_gemm_tcq_combt_14336_1_4096_9_6_7", "decompress_gemm_tcq_comb_4096_8_4096_10_9_10",
+            "decompress_tcq_9_2", "decompress_tcq_combt_11_9_10", "decompress_gemm_4096_2_4096_4_sq_dup",
+            "decompress_gemm_4096_1_4096_8_sq", "decompress_gemm_28672_1_4096_12_vq2", "decompress_gemv_4096_4096_4_sq",
+            "decompress_6_sq", "vq_pack_gemm_simt_4_2_8", "vq_pack_dequant_simt_4_12", "sq_pack_gemm_simt"]
+    bad = ["decompress_gemm_tcq_4096_1_4096_9_11", "decompress_gemm_tcq_4096_1_4096_10_7", "decompress_tcq_12_9",
+           "decompress_gemm_tcq_4100_1_4096_9_6", "decompress_gemm_tcq_4096_9_4096_9_6",
+           "decompress_gemm_tcq_combt_4096_1_4096_9_6_8", "decompress_gemm_4096_1_4096_5_sq_dup",
+           "decompress_gemm_4096_1_4096_13_vq2", "vq_pack_gemm_simt_1_4_5", "vq_pack_gemm_simt_1_3_8", "nonsense"]
+    for name in good:
+        assert qp.ops.ensure_op(name), name
+        assert getattr(torch.ops.ours_lib, name) is not None
+    for name in bad:
+        assert not qp.ops.ensure_op(name), name
+        with pytest.raises(AttributeError):
+            getattr(torch.ops.ours_lib, name)
+
+
+def test_fake_tensor_shapes_and_dtypes():
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        c = torch.empty(4096 * 4096 * 6 // 32, dtype=torch.int16, device="cuda")
+        x = torch.empty(3, 4096, dtype=torch.float16, device="cuda")
+        cb = torch.empty(512, 2, dtype=torch.float16, device="cuda")
+        y = qp.ops.get_op("decompress_gemm_tcq_4096_3_4096_9_6")(c, x, cb)
+        assert tuple(y.shape) == (3, 4096) and y.dtype == torch.float32
+        w = qp.ops.get_op("decompress_tcq_9_6")(c, cb, 4096, 4096)
+        assert tuple(w.shape) == (4096, 4096) and w.dtype == torch.float16
+        q = torch.empty(4096, 512, dtype=torch.int32, device="cuda")
+        lut = torch.empty(16, dtype=torch.float16, device="cuda")
+        y = qp.ops.get_op("sq_pack_gemm_simt")(x.reshape(3, 1, 4096), q, lut, 4)
+        assert tuple(y.shape) == (3, 1, 4096) and y.dtype == torch.float16
+
+
+def test_no_cpu_implementation():
+    """The product path is the HIP library only: CPU tensors are refused, not silently computed."""
+    op = qp.ops.get_op("decompress_gemm_tcq_64_1_64_9_4")
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        op(torch.zeros(32, 16, dtype=torch.int16), torch.zeros(1, 64), torch.zeros(512, 2, dtype=torch.float16))
+
+
+def test_quantizer_strings_and_layer_shapes():
+    mo = qp.mem_op
+    assert mo.get_quant_info("tcq_6_none_0.9")["tlut_bits"] == 9 and mo.get_quant_info("tcq_9_none_0.9")["tlut_bits"] == 10
+    assert mo.get_quant_info("tcomb_9_10_0.5_none_0.9")["tlut_bits"] == 11
+    assert mo.bits_per_weight("tcomb_6_7_0.5_none_0.9") == 3.25 and mo.bits_per_weight("ldlq_2_12_none_1.0") == 6.0
+    weights = sum(v["in_features"] * v["out_features"] for k, v in mo.get_layer_info("3_8b").items() if k != "nlayers")
+    assert weights == 218103808
+    info = mo.get_dummy_quant_results("3_8b", "mlp.down_proj", "tcomb_6_7_0.5_none_0.9")["linear_info"]
+    assert tuple(info["trellis1"].shape) == (4096 // 16 * 7168 // 16, 48) and info["trellis1"].dtype == torch.int16
+    assert tuple(info["trellis2"].shape) == (4096 // 16 * 7168 // 16, 56) and tuple(info["tlut"].shape) == (512, 2)
+    info = mo.get_dummy_quant_results("3_8b", "self_attn.k_proj", "ldlq_2_9_none_1.0")["linear_info"]
+    assert tuple(info["qweight"].shape) == (1024, 9 * 4096 // 64) and tuple(info["lut"].shape) == (512, 2)
+    assert qp.linear.linear_class_for("tcomb_6_7_0.5_none_0.9") is qp.CombtLinearTCQ
+    assert qp.linear.linear_class_for("comb_6_7_0.5_none_0.9") is qp.CombLinearTCQ
+    assert qp.linear.linear_class_for("tcq_6_none_0.9") is qp.QTIPLinearTCQ
+    assert qp.linear.linear_class_for("ldlq_1_4_none_1.0", use_simt=True) is qp.VQLinearPackSIMT
+
+
+def test_modules_round_trip_info_and_merge():
+    for qstr, cls in (("tcq_5_none_0.9", qp.QTIPLinearTCQ), ("tcomb_6_7_0.5_none_0.9", qp.CombtLinearTCQ),
+                      ("comb_3_4_0.5_none_0.9", qp.CombLinearTCQ), ("ldlq_2_8_none_1.0", qp.VQLinearPackTensorCore)):
+        a = qp.mem_op.dummy_linear_info(256, 128, qstr, seed=1)
+        layer = cls.gen_layer_from_info(a) if cls is not qp.VQLinearPackTensorCore else cls.gen_layer_from_info(a)
+        back = layer._info()
+        for key, val in a.items():
+            if isinstance(val, torch.Tensor):
+                assert torch.equal(back[key], val), key
+        if hasattr(cls, "merge_infos") and cls is not qp.CombLinearTCQ:
+            b = qp.mem_op.dummy_linear_info(256, 64, qstr, seed=2)
+            tab = "lut" if "lut" in a else "tlut"
+            b[tab] = a[tab].clone()
+            m = cls.merge_infos(a, b)
+            assert m["out_features"] == 192
+            fused = cls.gen_layer_from_info(m)
+            assert fused.out_features == 192
+
+
+def test_merged_rows_decode_as_concatenation():
+    """merge_infos == row concatenation of W (what QKV / up+gate fusion relies on), checked with the oracle."""
+    qstr = "tcomb_6_7_0.5_none_0.9"
+    a = qp.mem_op.dummy_linear_info(256, 128, qstr, seed=1)
+    b = qp.mem_op.dummy_linear_info(256, 64, qstr, seed=2)
+    b["tlut"] = a["tlut"].clone()
+    m = qp.CombtLinearTCQ.merge_infos(a, b)
+
+    def W(i):
+        return oracle.tcq_dequant(i["trellis1"].numpy(), i["tlut"].numpy(), i["out_features"], 256, 9, 6,
+                                  c2=i["trellis2"].numpy(), KV2=7, split=2)
+
+    assert np.array_equal(W(m).view(np.uint16), np.concatenate([W(a), W(b)], 0).view(np.uint16))
+
+
+def test_row_shards_decode_as_row_slices():
+    for qstr in ("tcq_6_none_0.9", "tcomb_6_7_0.5_none_0.9", "ldlq_1_4_none_1.0", "ldlq_2_9_none_1.0"):
+        k, m = 256, 32 * 7  # 7 supertile rows over 3 ranks -> ragged shards
+        info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=3)
+
+        def W(i):
+            mm = i["out_features"]
+            if "trellis1" in i:
+                return oracle.tcq_dequant(i["trellis1"].numpy(), i["tlut"].numpy(), mm, k, 9, 6, c2=i["trellis2"].numpy(),
+                                          KV2=7, split=2)
+            if "trellis" in i:
+                return oracle.tcq_dequant(i["trellis"].numpy(), i["tlut"].numpy(), mm, k, 9, 6)
+            return oracle.lut_tc_dequant(i["qweight"].numpy(), i["lut"].numpy(), mm, k, i["lut_bits"], i["vec_sz"])
+
+        full = W(info)
+        sizes = qp.shard.shard_rows(m, 3)
+        assert sizes == [96, 64, 64] and sum(sizes) == m
+        for rank in range(3):
+            r0, r1 = qp.shard.shard_bounds(m, 3, rank)
+            part = W(qp.shard.shard_linear_info(info, rank, 3))
+            assert np.array_equal(part.view(np.uint16), full[r0:r1].view(np.uint16))
