@@ -243,7 +243,9 @@ def main():
 
     tokens = args.steps * n * (1 if tp else world)
     value = tokens / wall
-    nlaunch = sum(len(m) for m in layers)
+    nlinear = sum(len(m) for m in layers)
+    multi = args.launch == "multi" and args.streams < 3 and not tp
+    nlaunch = nlinear * 4 // 7 if multi else nlinear  # kernel launches per token
     abytes = algorithmic_bytes(qp, layers, n) * (world if tp else 1)  # per token
     t_token = dev_s / args.steps
     achieved = abytes / (world if tp else 1) / t_token / 1e9  # per GPU
@@ -257,11 +259,10 @@ def main():
         "config": {"workload": f"{args.workload}: {nlayers} layers x 7 quantized linears ({qstr}), batch {n}, "
                                f"{'HIP-graph replay' if graph is not None else 'eager'}, {args.streams} stream(s)",
                    "parallelism": (f"tp{world} row-sharded + all-gather" if tp else f"dp{world} replicas"),
-                   "launches_per_token": (nlaunch * 4 // 7 if (args.launch == "multi" and args.streams < 3 and not tp) else nlaunch),
-                   "launch_mode": args.launch},
+                   "linears_per_token": nlinear, "launches_per_token": nlaunch, "launch_mode": args.launch},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
-                     "kernel": "tc_gemv_kernel (all launches of a token)",
+                     "kernel": "qpal::tc_gemv_kernel<TcqCodec<9,6>,TcqCodec<9,7>> (every launch of a token)",
                      "algorithmic_bytes_per_launch": abytes / (world if tp else 1) / nlaunch,
                      "avg_launch_us": t_token / nlaunch * 1e6},
     }
