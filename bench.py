@@ -54,13 +54,18 @@ def parse_args():
     ap.add_argument("--launch", default="multi", choices=["single", "multi"],
                     help="single: one launch per linear (7/layer); multi: q|k|v and gate|up (projections of one input) "
                          "go out as one multi-job launch each (4 launches/layer, same arithmetic, same buffers)")
+    ap.add_argument("--distinct-codebooks", action="store_true",
+                    help="give every linear its own random codebook (default: one codebook per model, as in real "
+                         "Q-Palette checkpoints where every layer stores a copy of the same k-means codebook)")
     ap.add_argument("--layers", type=int, default=0, help="override the number of layers (0 = model's)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo to rehearse ranks on one GPU")
+    ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: put every rank on this GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
 
 
-def build_model(qp, torch, model_key, qstr, nlayers, device, shard=None):
+def build_model(qp, torch, model_key, qstr, nlayers, device, shard=None, distinct_codebooks=False):
     """-> list over layers of list of (module, in_features); every layer has distinct buffers."""
     li = qp.mem_op.get_layer_info(model_key)
     layers, infos0 = [], None
@@ -71,10 +76,13 @@ def build_model(qp, torch, model_key, qstr, nlayers, device, shard=None):
             if shard is not None:  # row shard (out_features) of this rank
                 rank, world = shard
                 m = qp.shard.shard_rows(m, world)[rank]
-            info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=layer * 16 + j, device=device)
+            info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=layer * 16 + j, device=device,
+                                               codebook_seed=None if distinct_codebooks else 777)
             mod = qp.make_linear_from_info(qstr, info).to(device)
             mods.append((mod, k, info if layer == 0 else None))
         layers.append(mods)
+    if not distinct_codebooks:  # what a checkpoint loader does: identical codebooks share one tensor
+        qp.share_codebooks([m for mods in layers for m, _, _ in mods])
     return layers
 
 
@@ -142,11 +150,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path is the product; there is no CPU fallback)")
+    if args.force_device >= 0:
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     import qpalette_amd as qp
@@ -156,7 +169,8 @@ def main():
     nlayers = args.layers or qp.mem_op.get_layer_info(model_key)["nlayers"]
     tp = args.parallel == "tp" and world > 1
     torch.manual_seed(1234)
-    layers = build_model(qp, torch, model_key, qstr, nlayers, device, shard=(rank, world) if tp else None)
+    layers = build_model(qp, torch, model_key, qstr, nlayers, device, shard=(rank, world) if tp else None,
+                         distinct_codebooks=args.distinct_codebooks)
     n = args.batch
     xs = {}
     for mod, k, _ in layers[0]:
@@ -237,7 +251,7 @@ def main():
         dev_s = e0.elapsed_time(e1) / 1e3
 
     if world > 1:
-        t = torch.tensor([wall, dev_s], device=device, dtype=torch.float64)
+        t = torch.tensor([wall, dev_s], device=device if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_s = float(t[0]), float(t[1])
 
@@ -255,7 +269,8 @@ def main():
         "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if tp else "weak", "vs_baseline": None, "dtype": "f16 weights x f16 activations, f32 accumulate",
-        "data": "synthetic (random packed bits, random codebooks, random activations)",
+        "data": "synthetic (random packed bits, random activations, " + ("one random codebook per linear" if
+                args.distinct_codebooks else "one random codebook shared by all layers as in real checkpoints") + ")",
         "config": {"workload": f"{args.workload}: {nlayers} layers x 7 quantized linears ({qstr}), batch {n}, "
                                f"{'HIP-graph replay' if graph is not None else 'eager'}, {args.streams} stream(s)",
                    "parallelism": (f"tp{world} row-sharded + all-gather" if tp else f"dp{world} replicas"),

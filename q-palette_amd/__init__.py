@@ -24,6 +24,7 @@ from .linear import (  # noqa: F401
     VQLinearPackTensorCore,
     make_linear_from_info,
     multi_gemv,
+    share_codebooks,
 )
 
 __version__ = "0.1.0"

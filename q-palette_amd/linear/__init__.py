@@ -22,6 +22,33 @@ def make_linear_from_info(quantizer_str, linear_info, use_simt=False):
     return linear_class_for(quantizer_str, use_simt).gen_layer_from_info(linear_info)
 
 
+def share_codebooks(modules):
+    """Make linears whose codebooks are bit-identical share ONE device tensor.
+
+    Real Q-Palette checkpoints store a copy of the same k-means codebook in every layer (tcq_quant.py:131:
+    ``tcq_linear.tlut.data.copy_(cb.tlut)``; assets/lut_cache/*.pt).  Sharing the storage lets a multi-job
+    launch see equal pointers and keep the LDS codebook image across jobs instead of rebuilding it.
+    Returns the number of distinct codebooks left."""
+    import torch
+
+    seen = []
+    for mod in modules:
+        name = "tlut" if hasattr(mod, "tlut") else ("lut" if hasattr(mod, "lut") else None)
+        if name is None:
+            continue
+        t = getattr(mod, name)
+        for ref in seen:
+            if ref.shape == t.shape and ref.dtype == t.dtype and ref.device == t.device and torch.equal(ref, t):
+                if isinstance(t, torch.nn.Parameter):
+                    t.data = ref.data
+                else:
+                    setattr(mod, name, ref)
+                break
+        else:
+            seen.append(t)
+    return len(seen)
+
+
 def multi_gemv(layers, x):
     """y_i = layers[i](x) for several quantized linears that share the input, batch <= 8.  Layers of one
     kind and codec (e.g. q|k|v or gate|up of one block under a single-scheme quantizer) go out as ONE
@@ -47,5 +74,5 @@ def multi_gemv(layers, x):
     return [l._gemv(x2, n) if n <= 8 else l(x2) for l in layers]
 
 
-__all__ = ["multi_gemv","QTIPLinearTCQ", "CombLinearTCQ", "CombtLinearTCQ", "VQLinearPackTensorCore", "VQLinearPackSIMT",
+__all__ = ["multi_gemv", "share_codebooks","QTIPLinearTCQ", "CombLinearTCQ", "CombtLinearTCQ", "VQLinearPackTensorCore", "VQLinearPackSIMT",
            "linear_class_for", "make_linear_from_info"]

@@ -82,14 +82,20 @@ def _rand_i32(shape, gen, device):
     return torch.randint(-2 ** 31, 2 ** 31, shape, dtype=torch.int32, device=device, generator=gen)
 
 
-def dummy_linear_info(in_features, out_features, quantizer_str, seed=0, device="cpu"):
-    """Random packed weights with the reference's shapes/dtypes for one linear (``linear_info`` dict)."""
+def dummy_linear_info(in_features, out_features, quantizer_str, seed=0, device="cpu", codebook_seed=None):
+    """Random packed weights with the reference's shapes/dtypes for one linear (``linear_info`` dict).
+    codebook_seed: draw the codebook from its own generator (same seed -> same codebook in every layer, as in
+    real checkpoints where every layer carries a copy of one k-means codebook)."""
     qi = get_quant_info(quantizer_str)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
+    cgen = gen
+    if codebook_seed is not None:
+        cgen = torch.Generator(device=device)
+        cgen.manual_seed(codebook_seed)
 
     def randn(shape):
-        return torch.randn(shape, generator=gen, device=device, dtype=torch.float32).to(torch.float16)
+        return torch.randn(shape, generator=cgen, device=device, dtype=torch.float32).to(torch.float16)
 
     if quantizer_str.startswith("ldlq") or quantizer_str.startswith("sq") or quantizer_str.startswith("vq"):
         bits, vec = qi["lut_bits"], qi["vec_sz"]
