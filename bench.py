@@ -35,6 +35,9 @@ WORKLOADS = {
     "llama3.1-8b_tcq_6": ("3_8b", "tcq_6_none_0.9"),
     "llama3.1-8b_ldlq_1_4": ("3_8b", "ldlq_1_4_none_1.0"),
     "llama3.1-70b_tcq_6": ("3_70b", "tcq_6_none_0.9"),
+    # the reference's published mixed-scheme results (perf/qdicts/*.json, exported from msq_results/):
+    "llama3.1-8b_figure1c": ("3_8b", "qdict:figure1c"),   # latency-aware MSQ, no fusion, avg 2.86 b/w
+    "llama3.1-8b_figure1d": ("3_8b", "qdict:figure1d"),   # fusion-aware MSQ (merged qkv/kv + up|gate), avg 2.96 b/w
 }
 LINEAR_ORDER = ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj",
                 "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"]
@@ -66,31 +69,65 @@ def parse_args():
 
 
 def build_model(qp, torch, model_key, qstr, nlayers, device, shard=None, distinct_codebooks=False):
-    """-> list over layers of list of (module, in_features); every layer has distinct buffers."""
+    """-> list over layers of 4 groups [attention inputs (q,k,v), o, mlp inputs (gate,up), down]; a group is a
+    list of (module, in_features, linear_info-or-None) that share one input vector.  Every layer has
+    distinct packed buffers.  qstr "qdict:<name>": quantizer per linear (+ fused layers) from perf/qdicts."""
     li = qp.mem_op.get_layer_info(model_key)
-    layers, infos0 = [], None
-    for layer in range(nlayers):
-        mods = []
-        for j, key in enumerate(LINEAR_ORDER):
+    qdict, merge_info = None, None
+    if qstr.startswith("qdict:"):
+        with open(os.path.join(ROOT, "perf", "qdicts", qstr[6:] + ".json")) as f:
+            data = json.load(f)
+        qdict, merge_info = data["qdict"], data["merge_info"]
+    cseed = None if distinct_codebooks else 777
+
+    def make(layer, keys):
+        """one (possibly fused) linear from the row-concatenation of `keys`"""
+        infos, q0, simt0 = [], None, None
+        for key in keys:
+            q, simt = (qdict[f"{layer}_{key}"] if qdict is not None else (qstr, "0"))
+            q0, simt0 = (q, simt) if q0 is None else (q0, simt0)
+            assert (q, simt) == (q0, simt0), "fused layers must share the quantizer"
             k, m = li[key]["in_features"], li[key]["out_features"]
-            if shard is not None:  # row shard (out_features) of this rank
-                rank, world = shard
-                m = qp.shard.shard_rows(m, world)[rank]
-            info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=layer * 16 + j, device=device,
-                                               codebook_seed=None if distinct_codebooks else 777)
-            mod = qp.make_linear_from_info(qstr, info).to(device)
-            mods.append((mod, k, info if layer == 0 else None))
-        layers.append(mods)
+            if shard is not None:
+                m = qp.shard.shard_rows(m, shard[1])[shard[0]]
+            infos.append(qp.mem_op.dummy_linear_info(k, m, q, seed=layer * 16 + LINEAR_ORDER.index(key), device=device,
+                                                     codebook_seed=cseed))
+        cls = qp.linear.linear_class_for(q0, use_simt=False)
+        info = infos[0]
+        for other in infos[1:]:
+            info = cls.merge_infos(info, other)
+        if simt0 == "1" and "ldlq" in q0:
+            mod = qp.VQLinearPackSIMT.gen_layer_from_info(info, device=device)
+        else:
+            mod = cls.gen_layer_from_info(info).to(device)
+        return (mod, info["in_features"], info if layer == 0 else None)
+
+    layers = []
+    for layer in range(nlayers):
+        merges = set(merge_info[layer]) if merge_info is not None else set()
+        q, k, v, o, g, u, d = LINEAR_ORDER
+        if "merge_qkv" in merges:
+            attn = [make(layer, [q, k, v])]
+        elif "merge_kv" in merges:
+            attn = [make(layer, [q]), make(layer, [k, v])]
+        elif "merge_qk" in merges:
+            attn = [make(layer, [q, k]), make(layer, [v])]
+        elif "merge_qv" in merges:
+            attn = [make(layer, [q, v]), make(layer, [k])]
+        else:
+            attn = [make(layer, [q]), make(layer, [k]), make(layer, [v])]
+        mlp = [make(layer, [u, g])] if "merge_ug" in merges else [make(layer, [g]), make(layer, [u])]
+        layers.append([attn, [make(layer, [o])], mlp, [make(layer, [d])]])
     if not distinct_codebooks:  # what a checkpoint loader does: identical codebooks share one tensor
-        qp.share_codebooks([m for mods in layers for m, _, _ in mods])
+        qp.share_codebooks([m for groups in layers for grp in groups for m, _, _ in grp])
     return layers
 
 
 def algorithmic_bytes(qp, layers, batch):
     """Bytes every token must read/write at least once: packed weights + codebook + x (fp16) + out."""
     total = 0
-    for mods in layers:
-        for mod, k, _ in mods:
+    for groups in layers:
+        for mod, k, _ in (u for grp in groups for u in grp):
             for name in ("trellis", "trellis1", "trellis2", "qweight", "tlut", "lut"):
                 t = getattr(mod, name, None)
                 if t is not None:
@@ -105,7 +142,7 @@ def cpu_baseline(qp, layers, batch, seconds):
     import numpy as np
     from oracle import oracle
 
-    mods = layers[0]
+    mods = [u for grp in layers[0] for u in grp]
     host = []
     for mod, k, info in mods:
         m = mod.out_features
@@ -136,7 +173,7 @@ def cpu_baseline(qp, layers, batch, seconds):
     t_layer = el / reps
     nl = len(layers)
     return {"value": 1.0 / (t_layer * nl), "unit": "tokens/s", "cores": oracle.num_threads(), "kind": "port",
-            "sample": f"1 of {nl} layers (7 linears, batch {batch}) x {reps} reps = {el:.1f} s; "
+            "sample": f"1 of {nl} layers ({len(host)} linears, batch {batch}) x {reps} reps = {el:.1f} s; "
                       f"per-token time extrapolated as {nl} x per-layer time"}
 
 
@@ -173,9 +210,10 @@ def main():
                          distinct_codebooks=args.distinct_codebooks)
     n = args.batch
     xs = {}
-    for mod, k, _ in layers[0]:
-        if k not in xs:
-            xs[k] = torch.randn(n, k, device=device).half()
+    for groups in layers:
+        for mod, k, _ in (u for grp in groups for u in grp):
+            if k not in xs:
+                xs[k] = torch.randn(n, k, device=device).half()
     gather = qp.shard.make_gatherer(world, device) if tp else None
 
     main_stream = torch.cuda.Stream(device)
@@ -183,40 +221,34 @@ def main():
 
     def token():
         outs = []
-        for mods in layers:
-            if args.launch == "multi" and not side and gather is None:
-                outs += qp.multi_gemv([mods[0][0], mods[1][0], mods[2][0]], xs[mods[0][1]])
-                outs.append(mods[3][0]._gemv(xs[mods[3][1]], n))
-                outs += qp.multi_gemv([mods[4][0], mods[5][0]], xs[mods[4][1]])
-                outs.append(mods[6][0]._gemv(xs[mods[6][1]], n))
-                continue
-            if side:  # q | k | v  and  gate | up are independent given x: fork/join inside the graph
-                groups = [[0, 1, 2], [3], [4, 5], [6]]
-            else:
-                groups = [[0], [1], [2], [3], [4], [5], [6]]
-            for grp in groups:
-                if len(grp) > 1:
+        for groups in layers:
+            for gi, grp in enumerate(groups):
+                x = xs[grp[0][1]]
+                mods = [m for m, _, _ in grp]
+                if len(mods) > 1 and args.launch == "multi" and gather is None:
+                    outs += qp.multi_gemv(mods, x)        # projections of one input: one multi-job launch
+                    continue
+                if len(mods) > 1 and side:                # fork/join onto side streams inside the graph
                     ev = torch.cuda.Event()
                     ev.record(main_stream)
                     evs = []
-                    for j, idx in enumerate(grp):
-                        mod, k, _ = mods[idx]
+                    for j, mod in enumerate(mods):
                         if j == 0:
-                            outs.append(mod._gemv(xs[k], n))
-                        else:
-                            s = side[j - 1]
-                            s.wait_event(ev)
-                            with torch.cuda.stream(s):
-                                outs.append(mod._gemv(xs[k], n))
-                                e2 = torch.cuda.Event()
-                                e2.record(s)
-                                evs.append(e2)
+                            outs.append(mod._gemv(x, n))
+                            continue
+                        s_ = side[(j - 1) % len(side)]
+                        s_.wait_event(ev)
+                        with torch.cuda.stream(s_):
+                            outs.append(mod._gemv(x, n))
+                            e2 = torch.cuda.Event()
+                            e2.record(s_)
+                            evs.append(e2)
                     for e2 in evs:
                         main_stream.wait_event(e2)
-                else:
-                    mod, k, _ = mods[grp[0]]
-                    y = mod._gemv(xs[k], n)
-                    if gather is not None and grp[0] in (3, 6):  # o_proj / down_proj feed full-width consumers
+                    continue
+                for mod in mods:
+                    y = mod._gemv(x, n)
+                    if gather is not None and gi in (1, 3):  # o_proj / down_proj feed full-width consumers
                         y = gather(y)
                     outs.append(y)
         return outs
@@ -257,9 +289,10 @@ def main():
 
     tokens = args.steps * n * (1 if tp else world)
     value = tokens / wall
-    nlinear = sum(len(m) for m in layers)
-    multi = args.launch == "multi" and args.streams < 3 and not tp
-    nlaunch = nlinear * 4 // 7 if multi else nlinear  # kernel launches per token
+    nlinear = sum(len(grp) for groups in layers for grp in groups)
+    multi = args.launch == "multi" and not tp
+    nlaunch = sum(len(qp.linear.launch_groups([m for m, _, _ in grp])) if multi else len(grp)
+                  for groups in layers for grp in groups)  # GEMV kernel launches per token
     abytes = algorithmic_bytes(qp, layers, n) * (world if tp else 1)  # per token
     t_token = dev_s / args.steps
     achieved = abytes / (world if tp else 1) / t_token / 1e9  # per GPU
@@ -271,13 +304,13 @@ def main():
         "scaling": "strong" if tp else "weak", "vs_baseline": None, "dtype": "f16 weights x f16 activations, f32 accumulate",
         "data": "synthetic (random packed bits, random activations, " + ("one random codebook per linear" if
                 args.distinct_codebooks else "one random codebook shared by all layers as in real checkpoints") + ")",
-        "config": {"workload": f"{args.workload}: {nlayers} layers x 7 quantized linears ({qstr}), batch {n}, "
+        "config": {"workload": f"{args.workload}: {nlayers} layers, {nlinear} quantized linears ({qstr}), batch {n}, "
                                f"{'HIP-graph replay' if graph is not None else 'eager'}, {args.streams} stream(s)",
                    "parallelism": (f"tp{world} row-sharded + all-gather" if tp else f"dp{world} replicas"),
                    "linears_per_token": nlinear, "launches_per_token": nlaunch, "launch_mode": args.launch},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
-                     "kernel": "qpal::tc_gemv_kernel<TcqCodec<9,6>,TcqCodec<9,7>> (every launch of a token)",
+                     "kernel": "qpal::tc_gemv_kernel (every GEMV launch of a token)",
                      "algorithmic_bytes_per_launch": abytes / (world if tp else 1) / nlaunch,
                      "avg_launch_us": t_token / nlaunch * 1e6},
     }

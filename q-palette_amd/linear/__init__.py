@@ -49,30 +49,62 @@ def share_codebooks(modules):
     return len(seen)
 
 
+def _codec_key(layer):
+    """Layers with equal keys run the same kernel instantiation and can share one multi-job launch."""
+    if isinstance(layer, QTIPLinearTCQ):
+        return ("tcq", layer.in_features, layer.tlut_bits, layer.KV)
+    if isinstance(layer, CombtLinearTCQ) and layer.use_comb_kernel:
+        return ("tcombt", layer.in_features, layer.tlut_bits, tuple(layer.KV))
+    if isinstance(layer, VQLinearPackTensorCore):
+        return ("lut_tc", layer.in_features, layer.lut_bits, layer.vec_sz)
+    return ("single", id(layer))
+
+
+def launch_groups(layers):
+    """Partition `layers` (projections of one input) into multi-job launches: lists of indices, at most 8 each."""
+    groups = {}
+    for i, layer in enumerate(layers):
+        groups.setdefault(_codec_key(layer), []).append(i)
+    out = []
+    for key, idxs in groups.items():
+        if key[0] == "single":
+            out.append(idxs)
+        else:
+            out += [idxs[a:a + 8] for a in range(0, len(idxs), 8)]
+    return out
+
+
 def multi_gemv(layers, x):
     """y_i = layers[i](x) for several quantized linears that share the input, batch <= 8.  Layers of one
-    kind and codec (e.g. q|k|v or gate|up of one block under a single-scheme quantizer) go out as ONE
-    kernel launch; anything else falls back to one launch per layer.  Returns fp32 [n, m_i] tensors."""
+    kind and codec (e.g. q|k|v or gate|up of one block) go out as ONE kernel launch per codec
+    (C-ABI qpal_*_gemv_multi); anything else is one launch per layer.  Returns fp32/fp16 [n, m_i] tensors in
+    the order of `layers`."""
     from .. import ops
 
     x2 = x.reshape(-1, layers[0].in_features)
     n = x2.shape[0]
-    first = layers[0]
-    same_kind = all(type(l) is type(first) and l.in_features == first.in_features for l in layers)
-    if n <= 8 and same_kind and len(layers) <= 8:
-        if isinstance(first, QTIPLinearTCQ) and all((l.KV, l.tlut_bits) == (first.KV, first.tlut_bits) for l in layers):
-            return ops.tcq_gemv_multi([(l.trellis, None, l.tlut, l.out_features) for l in layers], x2,
-                                      first.tlut_bits, first.KV)
-        if (isinstance(first, CombtLinearTCQ) and all(l.use_comb_kernel and (l.KV, l.tlut_bits) ==
-                                                      (first.KV, first.tlut_bits) for l in layers)):
-            return ops.tcq_gemv_multi([(l.trellis1, l.trellis2, l.tlut, l.out_features) for l in layers], x2,
-                                      first.tlut_bits, first.KV[0], first.KV[1], split=2)
-        if (isinstance(first, VQLinearPackTensorCore) and
-                all((l.lut_bits, l.vec_sz) == (first.lut_bits, first.vec_sz) for l in layers)):
-            return ops.lut_tc_gemv_multi([(l.qweight, l.lut, l.out_features) for l in layers], x2, first.lut_bits,
-                                         first.vec_sz)
-    return [l._gemv(x2, n) if n <= 8 else l(x2) for l in layers]
+    if n > 8:
+        return [l(x2) for l in layers]
+    outs = [None] * len(layers)
+    for idxs in launch_groups(layers):
+        first = layers[idxs[0]]
+        kind = _codec_key(first)[0]
+        grp = [layers[i] for i in idxs]
+        if kind == "tcq":
+            ys = ops.tcq_gemv_multi([(l.trellis, None, l.tlut, l.out_features) for l in grp], x2, first.tlut_bits,
+                                    first.KV)
+        elif kind == "tcombt":
+            ys = ops.tcq_gemv_multi([(l.trellis1, l.trellis2, l.tlut, l.out_features) for l in grp], x2,
+                                    first.tlut_bits, first.KV[0], first.KV[1], split=2)
+        elif kind == "lut_tc":
+            ys = ops.lut_tc_gemv_multi([(l.qweight, l.lut, l.out_features) for l in grp], x2, first.lut_bits,
+                                       first.vec_sz)
+        else:
+            ys = [first._gemv(x2, n)]
+        for i, y in zip(idxs, ys):
+            outs[i] = y
+    return outs
 
 
-__all__ = ["multi_gemv", "share_codebooks","QTIPLinearTCQ", "CombLinearTCQ", "CombtLinearTCQ", "VQLinearPackTensorCore", "VQLinearPackSIMT",
+__all__ = ["multi_gemv", "launch_groups", "share_codebooks","QTIPLinearTCQ", "CombLinearTCQ", "CombtLinearTCQ", "VQLinearPackTensorCore", "VQLinearPackSIMT",
            "linear_class_for", "make_linear_from_info"]
