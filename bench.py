@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--distinct-codebooks", action="store_true",
                     help="give every linear its own random codebook (default: one codebook per model, as in real "
                          "Q-Palette checkpoints where every layer stores a copy of the same k-means codebook)")
+    ap.add_argument("--no-prezero", action="store_true",
+                    help="A/B switch: let down_proj's split-K zero its output with its own memset node")
     ap.add_argument("--layers", type=int, default=0, help="override the number of layers (0 = model's)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo to rehearse ranks on one GPU")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: put every rank on this GPU")
@@ -222,11 +224,20 @@ def main():
     def token():
         outs = []
         for groups in layers:
+            down_out = None
             for gi, grp in enumerate(groups):
                 x = xs[grp[0][1]]
                 mods = [m for m, _, _ in grp]
-                if len(mods) > 1 and args.launch == "multi" and gather is None:
-                    outs += qp.multi_gemv(mods, x)        # projections of one input: one multi-job launch
+                if args.launch == "multi" and gather is None:
+                    # projections of one input: one multi-job launch per codec.  The mlp-input launch also
+                    # zeroes down_proj's output so that its split-K needs no memset node of its own.
+                    if gi == 2 and not args.no_prezero:
+                        down_out = torch.empty((n, groups[3][0][0].out_features), dtype=torch.float32, device=device)
+                        outs += qp.multi_gemv(mods, x, prezero=down_out)
+                    elif gi == 3 and down_out is not None:
+                        outs += qp.multi_gemv(mods, x, outs=[down_out], outs_zeroed=True)
+                    else:
+                        outs += qp.multi_gemv(mods, x)
                     continue
                 if len(mods) > 1 and side:                # fork/join onto side streams inside the graph
                     ev = torch.cuda.Event()

@@ -56,9 +56,14 @@ typedef struct qpal_tcq_job {
     const void *x;     /* fp16 [n][k] */
     const void *tlut;  /* fp16 [2^S][2] */
     int m, k;
+    int out_zeroed;    /* 1: the caller guarantees out is all zeros (e.g. pre-zeroed by an earlier launch, below):
+                          a split-K job then needs no memset node of its own */
 } qpal_tcq_job;
+/* prezero/prezero_bytes (may be NULL/0): a buffer this launch also fills with zeros, for a LATER launch on the
+ * same stream that accumulates into it with atomics (split-K of a few-rows x long-K layer such as down_proj).
+ * Saves that launch's memset node and the two extra graph boundaries around it.  bytes % 16 == 0.           */
 int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int KV1, int KV2, int split,
-                        void *stream);
+                        void *prezero, long prezero_bytes, void *stream);
 
 /* Trellis decode to fp16 W[m][k] row-major (bit-exact).  Replaces decompress_ptr / _comb_ptr /
  * _combt_ptr, kernels/tcq-kernels/src/inference.cu:1862-1891, 1970-2035.                         */
@@ -77,8 +82,10 @@ typedef struct qpal_lut_job {
     const void *x;        /* fp16 [n][k] */
     const void *lut;      /* fp16 [2^bits][vec] */
     int m, k;
+    int out_zeroed;       /* as in qpal_tcq_job */
 } qpal_lut_job;
-int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits, int vec, void *stream);
+int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits, int vec, void *prezero,
+                           long prezero_bytes, void *stream);
 
 /* Same format decoded to fp16 W[m][k].  Replaces decompress_ptr, vq-tensor inference.cu:1182-1226. */
 int qpal_lut_tc_dequant(void *out_f16, const void *qweight, const void *lut,

@@ -17,17 +17,18 @@ _P, _I = ctypes.c_void_p, ctypes.c_int
 
 class TcqJob(ctypes.Structure):
     """qpal_tcq_job (include/qpal.h)"""
-    _fields_ = [("out", _P), ("c1", _P), ("c2", _P), ("x", _P), ("tlut", _P), ("m", _I), ("k", _I)]
+    _fields_ = [("out", _P), ("c1", _P), ("c2", _P), ("x", _P), ("tlut", _P), ("m", _I), ("k", _I),
+                ("out_zeroed", _I)]
 
 
 class LutJob(ctypes.Structure):
     """qpal_lut_job (include/qpal.h)"""
-    _fields_ = [("out", _P), ("qweight", _P), ("x", _P), ("lut", _P), ("m", _I), ("k", _I)]
+    _fields_ = [("out", _P), ("qweight", _P), ("x", _P), ("lut", _P), ("m", _I), ("k", _I), ("out_zeroed", _I)]
 
 
 _SIGNATURES = {
-    "qpal_tcq_gemv_multi": [ctypes.POINTER(TcqJob), _I, _I, _I, _I, _I, _I, _P],
-    "qpal_lut_tc_gemv_multi": [ctypes.POINTER(LutJob), _I, _I, _I, _I, _P],
+    "qpal_tcq_gemv_multi": [ctypes.POINTER(TcqJob), _I, _I, _I, _I, _I, _I, _P, ctypes.c_long, _P],
+    "qpal_lut_tc_gemv_multi": [ctypes.POINTER(LutJob), _I, _I, _I, _I, _P, ctypes.c_long, _P],
     "qpal_tcq_gemv": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "qpal_tcq_dequant": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "qpal_lut_tc_gemv": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

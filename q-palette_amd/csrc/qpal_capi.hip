@@ -123,8 +123,8 @@ void tcq_fill(TcParams &p, float *out, long ldo, const void *c1, const void *c2,
     p.x_lds = x_fits_lds(n, k);
 }
 
-int zero_if_split(const TcParams &p, int m, hipStream_t stream) {
-    if (p.sk > 1) {
+int zero_if_split(const TcParams &p, int m, hipStream_t stream, int out_zeroed = 0) {
+    if (p.sk > 1 && !out_zeroed) {
         for (int b = 0; b < p.n; b++) {
             hipError_t e = hipMemsetAsync(p.out + (long)b * p.ldo, 0, sizeof(float) * (size_t)m, stream);
             if (e != hipSuccess) return (int)e;
@@ -189,9 +189,11 @@ int qpal_tcq_gemv(float *out, const void *c1, const void *c2, const void *x, con
     return tcq_gemv_one(out + m / 2, m, c2, nullptr, x, tlut, m / 2, n, k, k, 0, S, KV2, 0, s);
 }
 
-int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int KV1, int KV2, int split, void *stream) {
+int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int KV1, int KV2, int split, void *prezero,
+                        long prezero_bytes, void *stream) {
     if (!jobs) return QPAL_E_NULL;
     if (njobs < 1 || njobs > kMaxJobs) return QPAL_E_SHAPE;
+    if (prezero_bytes < 0 || prezero_bytes % 16 || (prezero_bytes && (!prezero || !aligned(prezero, 16)))) return QPAL_E_ALIGN;
     if (split == QPAL_SPLIT_ROWS) return QPAL_E_PARAM;  // the two row halves use different codecs: one call each
     if (n < 1 || n > 8) return QPAL_E_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -205,9 +207,11 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         if (!aligned(jb.x, 8) || !aligned(jb.out, 4) || (jb.k % 4)) return QPAL_E_ALIGN;
         if (split == QPAL_SPLIT_NONE) tcq_fill(mp.job[j], jb.out, jb.m, jb.c1, nullptr, jb.x, jb.tlut, jb.m, n, jb.k, jb.k, 0);
         else tcq_fill(mp.job[j], jb.out, jb.m, jb.c1, jb.c2, jb.x, jb.tlut, jb.m, n, jb.k, jb.k / 2, jb.k / 2);
-        rc = zero_if_split(mp.job[j], jb.m, s);
+        rc = zero_if_split(mp.job[j], jb.m, s, jb.out_zeroed);
         if (rc) return rc;
     }
+    mp.zero = static_cast<u32x4 *>(prezero);
+    mp.zero_chunks = (int)(prezero_bytes / 16);
     int grid;
     finish_multi(mp, grid);
     return launch_tcq_gemv(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, grid, s);
@@ -272,13 +276,15 @@ static int lut_args_ok(const void *out, const void *qweight, const void *x, cons
 
 int qpal_lut_tc_gemv(float *out, const void *qweight, const void *x, const void *lut, int m, int n, int k, int bits,
                      int vec, void *stream) {
-    qpal_lut_job job{out, qweight, x, lut, m, k};
-    return qpal_lut_tc_gemv_multi(&job, 1, n, bits, vec, stream);
+    qpal_lut_job job{out, qweight, x, lut, m, k, 0};
+    return qpal_lut_tc_gemv_multi(&job, 1, n, bits, vec, nullptr, 0, stream);
 }
 
-int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits, int vec, void *stream) {
+int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits, int vec, void *prezero,
+                           long prezero_bytes, void *stream) {
     if (!jobs) return QPAL_E_NULL;
     if (njobs < 1 || njobs > kMaxJobs) return QPAL_E_SHAPE;
+    if (prezero_bytes < 0 || prezero_bytes % 16 || (prezero_bytes && (!prezero || !aligned(prezero, 16)))) return QPAL_E_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     TcMultiParams mp{};
     mp.njobs = njobs;
@@ -287,9 +293,11 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
         int rc = lut_args_ok(jb.out, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k, bits, vec);
         if (rc) return rc;
         lut_fill(mp.job[j], jb.out, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k);
-        rc = zero_if_split(mp.job[j], jb.m, s);
+        rc = zero_if_split(mp.job[j], jb.m, s, jb.out_zeroed);
         if (rc) return rc;
     }
+    mp.zero = static_cast<u32x4 *>(prezero);
+    mp.zero_chunks = (int)(prezero_bytes / 16);
     int grid;
     finish_multi(mp, grid);
     return launch_lut_tc_gemv(mp, bits, vec, grid, s);

@@ -64,6 +64,8 @@ constexpr int kMaxJobs = 8;
 struct TcMultiParams {
     int njobs;
     int total_items;
+    int zero_chunks;   // 16-byte chunks of `zero` this launch fills with zeros (0: none)
+    u32x4 *zero;       // buffer pre-zeroed for a later split-K launch on the same stream
     int item_end[kMaxJobs];
     TcParams job[kMaxJobs];
 };
@@ -237,7 +239,7 @@ struct StreamView {
 #define QPAL_STAMP(i) do { } while (0)
 #endif
 
-constexpr int kScratchBytes = 30 * 1024;  // LDS left beside the 128 KiB codebook image: reduction buffer + x
+constexpr int kScratchBytes = 31 * 1024;  // LDS left beside the 128 KiB codebook image: reduction buffer + x
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
@@ -356,16 +358,30 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
     } w;
     const void *cur_tab = nullptr;      // codebook whose image is in LDS
     const uint16_t *cur_x = nullptr;    // activations staged in LDS
-    int cur_j = -1;
+    int cur_j = 0;
+    // one scalar-load round trip for everything the first item needs: the item table and job 0
+    int ie[kMaxJobs];
+#pragma unroll
+    for (int i = 0; i < kMaxJobs; i++) ie[i] = mp.item_end[i];
     TcParams p = mp.job[0];
-    for (int gitem = blockIdx.x; gitem < mp.total_items; gitem += gridDim.x) {
-        int j = 0;
-        while (gitem >= mp.item_end[j]) j++;
+    const int total_items = ie[kMaxJobs - 1];
+    if (mp.zero_chunks > 0) {  // pre-zero a buffer for a later split-K launch on this stream
+        for (int i = blockIdx.x * 1024 + tid; i < mp.zero_chunks; i += gridDim.x * 1024) mp.zero[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+    for (int gitem = blockIdx.x; gitem < total_items; gitem += gridDim.x) {
+        int j = 0, item_begin = 0;
+#pragma unroll
+        for (int i = 0; i < kMaxJobs - 1; i++) {
+            if (gitem >= ie[i]) {
+                j = i + 1;
+                item_begin = ie[i];
+            }
+        }
         if (j != cur_j) {
             p = mp.job[j];
             cur_j = j;
         }
-        const int item = gitem - (j > 0 ? mp.item_end[j - 1] : 0);
+        const int item = gitem - item_begin;
         float *red = reinterpret_cast<float *>(scratch);                           // [16][n][32]
         uint16_t *xs = reinterpret_cast<uint16_t *>(scratch + 16 * 32 * 4 * p.n);  // [n][k] + 32 zero halves
         const int wpr = 1 << p.log2_wpr;

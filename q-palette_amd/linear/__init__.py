@@ -74,36 +74,50 @@ def launch_groups(layers):
     return out
 
 
-def multi_gemv(layers, x):
+def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None):
     """y_i = layers[i](x) for several quantized linears that share the input, batch <= 8.  Layers of one
     kind and codec (e.g. q|k|v or gate|up of one block) go out as ONE kernel launch per codec
     (C-ABI qpal_*_gemv_multi); anything else is one launch per layer.  Returns fp32/fp16 [n, m_i] tensors in
-    the order of `layers`."""
+    the order of `layers`.
+
+    outs: fp32 [n, m_i] tensors to write into (outs_zeroed: they hold zeros, so a split-K layer needs no
+    memset of its own); prezero: a tensor the first multi-job launch also zeroes — the way a decode block
+    prepares down_proj's output during the gate|up launch."""
     from .. import ops
 
     x2 = x.reshape(-1, layers[0].in_features)
     n = x2.shape[0]
     if n > 8:
         return [l(x2) for l in layers]
-    outs = [None] * len(layers)
+    results = [None] * len(layers)
     for idxs in launch_groups(layers):
         first = layers[idxs[0]]
         kind = _codec_key(first)[0]
         grp = [layers[i] for i in idxs]
+        o = [outs[i] for i in idxs] if outs is not None else None
+        extra = dict(outs=o, outs_zeroed=outs_zeroed, prezero=prezero)
         if kind == "tcq":
             ys = ops.tcq_gemv_multi([(l.trellis, None, l.tlut, l.out_features) for l in grp], x2, first.tlut_bits,
-                                    first.KV)
+                                    first.KV, **extra)
+            prezero = None
         elif kind == "tcombt":
             ys = ops.tcq_gemv_multi([(l.trellis1, l.trellis2, l.tlut, l.out_features) for l in grp], x2,
-                                    first.tlut_bits, first.KV[0], first.KV[1], split=2)
+                                    first.tlut_bits, first.KV[0], first.KV[1], split=2, **extra)
+            prezero = None
         elif kind == "lut_tc":
             ys = ops.lut_tc_gemv_multi([(l.qweight, l.lut, l.out_features) for l in grp], x2, first.lut_bits,
-                                       first.vec_sz)
+                                       first.vec_sz, **extra)
+            prezero = None
         else:
             ys = [first._gemv(x2, n)]
+            if o is not None:
+                o[0].copy_(ys[0])
+                ys = o
         for i, y in zip(idxs, ys):
-            outs[i] = y
-    return outs
+            results[i] = y
+    if prezero is not None:  # no multi-job launch took it along
+        prezero.zero_()
+    return results
 
 
 __all__ = ["multi_gemv", "launch_groups", "share_codebooks","QTIPLinearTCQ", "CombLinearTCQ", "CombtLinearTCQ", "VQLinearPackTensorCore", "VQLinearPackSIMT",

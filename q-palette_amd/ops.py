@@ -224,14 +224,24 @@ def _simt_dequant_call(q_weight, lut, bits, vec, m, k):
 
 
 # ------------------------------------------------------------------------------------------------ multi-job launches
-def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0):
+def _prezero_args(prezero):
+    if prezero is None:
+        return None, 0
+    _chk(prezero.is_cuda and prezero.is_contiguous() and (prezero.numel() * prezero.element_size()) % 16 == 0
+         and prezero.data_ptr() % 16 == 0, "prezero must be a contiguous 16-byte-aligned CUDA tensor of 16*N bytes")
+    return prezero.data_ptr(), prezero.numel() * prezero.element_size()
+
+
+def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=False, prezero=None):
     """Several TCQ GEMVs of one codec and one input in ONE launch (C-ABI qpal_tcq_gemv_multi).
-    streams: list of (c1, c2_or_None, tlut, m); x: [n, k].  Returns the list of fp32 [n, m] outputs."""
+    streams: list of (c1, c2_or_None, tlut, m); x: [n, k].  Returns the list of fp32 [n, m] outputs.
+    outs: write into these tensors (outs_zeroed: they are all zeros already); prezero: a tensor this launch
+    also zeroes for a later split-K launch on the same stream."""
     n, k = x.shape
     _chk(1 <= n <= 8, "batch size must be in 1..8")
     xh = _dev(x.to(torch.float16), "x")
     jobs = (nat.TcqJob * len(streams))()
-    outs, keep = [], [xh]
+    results, keep = [], [xh]
     for j, (c1, c2, tlut, m) in enumerate(streams):
         c1 = _dev(c1, "compressed1")
         tl = _dev(tlut, "codebook")
@@ -242,35 +252,48 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0):
             c2 = _dev(c2, "compressed2")
             _tcq_stream_ok(c1, m, k // 2, KV1, "compressed1")
             _tcq_stream_ok(c2, m, k // 2, KV2, "compressed2")
-        out = torch.empty((n, m), dtype=torch.float32, device=x.device)
+        if outs is not None:
+            out = outs[j]
+            _chk(out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (n, m),
+                 f"outs[{j}] must be a contiguous fp32 CUDA tensor of shape ({n}, {m})")
+        else:
+            out = torch.empty((n, m), dtype=torch.float32, device=x.device)
         jobs[j] = nat.TcqJob(out.data_ptr(), c1.data_ptr(), c2.data_ptr() if c2 is not None else None,
-                             xh.data_ptr(), tl.data_ptr(), m, k)
-        outs.append(out)
+                             xh.data_ptr(), tl.data_ptr(), m, k, 1 if (outs is not None and outs_zeroed) else 0)
+        results.append(out)
         keep += [c1, c2, tl]
+    zp, zb = _prezero_args(prezero)
     with torch.cuda.device_of(x):
-        rc = nat.lib().qpal_tcq_gemv_multi(jobs, len(streams), n, S, KV1, KV2, split, _stream(x))
+        rc = nat.lib().qpal_tcq_gemv_multi(jobs, len(streams), n, S, KV1, KV2, split, zp, zb, _stream(x))
     nat.check(rc, "qpal_tcq_gemv_multi")
-    return outs
+    return results
 
 
-def lut_tc_gemv_multi(layers, x, bits, vec):
+def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezero=None):
     """Several VQ/SQ (tensor-core packing) GEMVs of one codec and one input in ONE launch.
-    layers: list of (qweight, lut, m); x: [n, k]."""
+    layers: list of (qweight, lut, m); x: [n, k].  outs / outs_zeroed / prezero as in tcq_gemv_multi."""
     n, k = x.shape
     _chk(1 <= n <= 8, "batch size must be in 1..8")
     xh = _dev(x.to(torch.float16), "x")
     jobs = (nat.LutJob * len(layers))()
-    outs, keep = [], [xh]
+    results, keep = [], [xh]
     for j, (q, lut, m) in enumerate(layers):
         q, cb = _lut_args(q, lut, m, k, bits, vec)
-        out = torch.empty((n, m), dtype=torch.float32, device=x.device)
-        jobs[j] = nat.LutJob(out.data_ptr(), q.data_ptr(), xh.data_ptr(), cb.data_ptr(), m, k)
-        outs.append(out)
+        if outs is not None:
+            out = outs[j]
+            _chk(out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (n, m),
+                 f"outs[{j}] must be a contiguous fp32 CUDA tensor of shape ({n}, {m})")
+        else:
+            out = torch.empty((n, m), dtype=torch.float32, device=x.device)
+        jobs[j] = nat.LutJob(out.data_ptr(), q.data_ptr(), xh.data_ptr(), cb.data_ptr(), m, k,
+                             1 if (outs is not None and outs_zeroed) else 0)
+        results.append(out)
         keep += [q, cb]
+    zp, zb = _prezero_args(prezero)
     with torch.cuda.device_of(x):
-        rc = nat.lib().qpal_lut_tc_gemv_multi(jobs, len(layers), n, bits, vec, _stream(x))
+        rc = nat.lib().qpal_lut_tc_gemv_multi(jobs, len(layers), n, bits, vec, zp, zb, _stream(x))
     nat.check(rc, "qpal_lut_tc_gemv_multi")
-    return outs
+    return results
 
 
 def tc_to_simt(qweight_tc, m, k, bits, vec):

@@ -251,3 +251,22 @@ def test_multi_job_launch_equals_single_launches(qp):
             ys = qp.multi_gemv(layers, x)
             for layer, y in zip(layers, ys):
                 assert torch.equal(y, layer._gemv(x, n))
+
+
+def test_prezero_and_out_zeroed(qp, oracle):
+    """A multi-job launch can pre-zero the output of a later split-K launch (gate|up zeroes down_proj's out)."""
+    qstr = "tcomb_6_7_0.5_none_0.9"
+    gate, up = (qp.make_linear_from_info(qstr, qp.mem_op.dummy_linear_info(4096, 14336, qstr, seed=s)).cuda()
+                for s in (1, 2))
+    info = qp.mem_op.dummy_linear_info(14336, 4096, qstr, seed=3)
+    down = qp.make_linear_from_info(qstr, info).cuda()
+    x = torch.randn(1, 4096, generator=torch.Generator().manual_seed(1)).cuda()
+    xd = torch.randn(1, 14336, generator=torch.Generator().manual_seed(2)).half()
+    out = torch.full((1, 4096), float("nan"), device="cuda")
+    qp.multi_gemv([gate, up], x, prezero=out)
+    assert torch.count_nonzero(out).item() == 0
+    (y,) = qp.multi_gemv([down], xd.cuda(), outs=[out], outs_zeroed=True)
+    assert y.data_ptr() == out.data_ptr()
+    W = _oracle_weight(oracle, qstr, info, 4096, 14336)
+    _check_gemv(y.cpu().numpy(), W, xd.numpy(), oracle)
+    assert torch.equal(y, down._gemv(xd.cuda(), 1))
