@@ -316,22 +316,31 @@ __device__ __forceinline__ void gemv_step(const uint32_t *lut, uint32_t laneoff,
     });
 }
 
-// steps [s0, s1) of one stream; `w` already holds step s0 (loaded before the codebook image was built)
+// steps [s0, s1) of one stream; `w` already holds step s0 (loaded before the codebook image was built).
+// Two register sets ping-pong (loop unrolled by 2) so the one-step-ahead prefetch costs no copies.
 template <class Codec, bool XLDS>
 __device__ __forceinline__ void gemv_run(uint32_t (&w)[Codec::NW], const uint32_t *lut, uint32_t laneoff,
                                          const StreamView &sv, const uint16_t *xg, const uint16_t *xs, int k, int n,
                                          int zero_off, int s0, int s1, int lane, float4_t &acc0, float4_t &acc1,
                                          float4_t &acc2, float4_t &acc3) {
-    for (int s = s0; s < s1; s++) {
-        uint32_t wn[Codec::NW];
-        const int sn = s + 1 < s1 ? s + 1 : s;  // last iteration re-reads its own step (L1 hit, unused)
-        load_step_w<Codec::NW>(sv, sn, lane, wn);
-        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's decode (hipcc sinks it otherwise)
-        u32x4 xb[2];
-        load_step_x<XLDS>(sv, xg, xs, k, n, zero_off, s, lane, xb);
-        gemv_step<Codec>(lut, laneoff, w, xb, acc0, acc1, acc2, acc3);
-#pragma unroll
-        for (int i = 0; i < Codec::NW; i++) w[i] = wn[i];
+    uint32_t wb[Codec::NW];
+    for (int s = s0; s < s1; s += 2) {
+        {
+            const int sn = s + 1 < s1 ? s + 1 : s;  // last step re-reads itself (L1 hit, unused)
+            load_step_w<Codec::NW>(sv, sn, lane, wb);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's decode (hipcc sinks it otherwise)
+            u32x4 xb[2];
+            load_step_x<XLDS>(sv, xg, xs, k, n, zero_off, s, lane, xb);
+            gemv_step<Codec>(lut, laneoff, w, xb, acc0, acc1, acc2, acc3);
+        }
+        if (s + 1 < s1) {
+            const int sn = s + 2 < s1 ? s + 2 : s + 1;
+            load_step_w<Codec::NW>(sv, sn, lane, w);
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 xb[2];
+            load_step_x<XLDS>(sv, xg, xs, k, n, zero_off, s + 1, lane, xb);
+            gemv_step<Codec>(lut, laneoff, wb, xb, acc0, acc1, acc2, acc3);
+        }
     }
 }
 
