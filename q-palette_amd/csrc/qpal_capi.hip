@@ -42,45 +42,22 @@ int x_fits_lds(int n, int k) {
 int nb_of(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : 8; }
 
 // Launch geometry of the fused GEMV.  16 waves per workgroup, one workgroup per CU.  A supertile row
-// (32 output rows) has st1 + st2 steps; it is cut into chunks (never straddling the two streams of a
-// combt layer) handled by `wpr` waves (power of two <= 16) of `sk` workgroups.  sk > 1 needs a zeroed
-// output + float atomics, i.e. one more graph node, so it is used only when a workgroup per row group
-// would leave each wave with more than kMaxStepsPerWave steps.
-constexpr int kMaxStepsPerWave = 4;
-
-// experiment knobs (perf/ scripts only): QPAL_FORCE_SK=<n>, QPAL_MAX_SPW=<n>
+// (32 output rows) has st1 + st2 steps, cut into chunks (never straddling the two streams of a combt layer)
+// for `wpr` waves (power of two <= 16) of `sk` workgroups.
+//
+// plan_launch() picks ONE wpr for all jobs of a launch: the largest that still fits the launch into a single
+// round of <= 256 workgroups (fewer, longer-running workgroups: the codebook image, x staging and the
+// first-byte latency are paid once, no cold restart between items).  Split-K over workgroups (sk > 1:
+// zeroed output + float atomics) is used when the launch would leave >= half of the CUs idle and the waves
+// have enough steps to share; it costs a memset node unless the caller pre-zeroed the output.
+// experiment knobs (perf/ scripts only): QPAL_FORCE_SK=<n>, QPAL_FORCE_WPR=<log2>
 static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
 }
 
-void gemv_geometry(int nrows, int st1, int st2, TcParams &p, int &grid) {
-    const int st = st1 + st2;
-    const long total = (long)nrows * st;
-    const long slots = (long)kNumCU * 16;
-    long spw = (total + slots - 1) / slots;  // steps per wave if the work were spread over the whole chip
-    if (spw < 1) spw = 1;
-    static const int max_spw = env_int("QPAL_MAX_SPW", kMaxStepsPerWave);
-    static const int force_sk = env_int("QPAL_FORCE_SK", 0);
-    if (spw > max_spw) spw = max_spw;
-    long chunks = (st + spw - 1) / spw;  // chunks per supertile row
-    if (st2 > 0 && chunks < 2) chunks = 2;
-    int log2_wpr = 0, sk = 1;
-    if (chunks <= 16) {
-        while ((1 << log2_wpr) < chunks) log2_wpr++;
-    } else {
-        log2_wpr = 4;
-        // one workgroup per row: waves loop over their steps; split K over workgroups only when that
-        // loop would get long AND the row count leaves CUs idle
-        const long per_wave = (st + 15) / 16;
-        if (force_sk > 0) {
-            sk = force_sk;
-        } else if (per_wave > max_spw && nrows < kNumCU) {
-            sk = (int)((per_wave + max_spw - 1) / max_spw);
-            const int cap = (int)(kNumCU / (nrows > 0 ? nrows : 1));
-            if (sk > cap) sk = cap < 1 ? 1 : cap;
-        }
-    }
+void set_chunks(TcParams &p, int log2_wpr, int sk) {
+    const int st1 = p.st1, st2 = p.st2, st = st1 + st2;
     const int nchunk = (1 << log2_wpr) * sk;
     int nc1 = nchunk;
     if (st2 > 0) {
@@ -96,8 +73,53 @@ void gemv_geometry(int nrows, int st1, int st2, TcParams &p, int &grid) {
     p.rem1 = st1 % nc1;
     p.base2 = st2 > 0 ? st2 / (nchunk - nc1) : 0;
     p.rem2 = st2 > 0 ? st2 % (nchunk - nc1) : 0;
-    p.nitems = ((nrows + rows_per_wg - 1) / rows_per_wg) * sk;
-    grid = p.nitems < kNumCU ? p.nitems : kNumCU;
+    p.nitems = ((p.nrows + rows_per_wg - 1) / rows_per_wg) * sk;
+}
+
+int items_at(const TcMultiParams &mp, int log2_wpr) {
+    const int rows_per_wg = 16 >> log2_wpr;
+    int items = 0;
+    for (int j = 0; j < mp.njobs; j++) items += (mp.job[j].nrows + rows_per_wg - 1) / rows_per_wg;
+    return items;
+}
+
+// out_zeroed[j]: the caller pre-zeroed job j's output (split-K is then free of a memset node)
+void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid) {
+    static const int force_sk = env_int("QPAL_FORCE_SK", 0);
+    static const int force_wpr = env_int("QPAL_FORCE_WPR", -1);
+    int min_st = 1 << 30;
+    bool two = false;
+    for (int j = 0; j < mp.njobs; j++) {
+        const int st = mp.job[j].st1 + mp.job[j].st2;
+        if (st < min_st) min_st = st;
+        two = two || mp.job[j].st2 > 0;
+    }
+    int log2_wpr = 4;
+    while (log2_wpr > 0 && items_at(mp, log2_wpr) > kNumCU) log2_wpr--;
+    while (log2_wpr > 0 && (1 << log2_wpr) > min_st) log2_wpr--;   // no more waves per row than steps
+    if (two && log2_wpr == 0) log2_wpr = 1;                         // a combt row needs >= 2 chunks
+    if (force_wpr >= 0) log2_wpr = force_wpr;
+    const int items = items_at(mp, log2_wpr);
+    for (int j = 0; j < mp.njobs; j++) {
+        TcParams &p = mp.job[j];
+        int sk = 1;
+        const int per_wave = (p.st1 + p.st2 + (1 << log2_wpr) - 1) >> log2_wpr;
+        if (items * 2 <= kNumCU && log2_wpr == 4) {
+            // idle CUs: share each row's K range between workgroups if the waves have steps to give away
+            const int want = kNumCU / items;
+            const int min_steps = (out_zeroed && out_zeroed[j]) ? 2 : 6;  // a memset node costs ~3 us
+            while (sk * 2 <= want && per_wave / (sk * 2) * 2 >= min_steps) sk *= 2;
+        }
+        if (force_sk > 0) sk = force_sk;
+        set_chunks(p, log2_wpr, sk);
+    }
+    int total = 0;
+    for (int j = 0; j < kMaxJobs; j++) {
+        if (j < mp.njobs) total += mp.job[j].nitems;
+        mp.item_end[j] = total;
+    }
+    mp.total_items = total;
+    grid = total < kNumCU ? total : kNumCU;
 }
 
 // fills one job's parameters + geometry; returns its item count through p.nitems
@@ -118,8 +140,6 @@ void tcq_fill(TcParams &p, float *out, long ldo, const void *c1, const void *c2,
     p.st1 = (p.nsc1 + 3) / 4;
     p.st2 = (p.nsc2 + 3) / 4;
     p.col2 = k1;
-    int grid;
-    gemv_geometry(p.nrows, p.st1, p.st2, p, grid);
     p.x_lds = x_fits_lds(n, k);
 }
 
@@ -133,25 +153,15 @@ int zero_if_split(const TcParams &p, int m, hipStream_t stream, int out_zeroed =
     return 0;
 }
 
-void finish_multi(TcMultiParams &mp, int &grid) {
-    int total = 0;
-    for (int j = 0; j < kMaxJobs; j++) {
-        if (j < mp.njobs) total += mp.job[j].nitems;
-        mp.item_end[j] = total;
-    }
-    mp.total_items = total;
-    grid = total < kNumCU ? total : kNumCU;
-}
-
 int tcq_gemv_one(float *out, long ldo, const void *c1, const void *c2, const void *x, const void *tlut, int m, int n,
                  int k, int k1, int k2, int S, int KV1, int KV2, hipStream_t stream) {
     TcMultiParams mp{};
     mp.njobs = 1;
     tcq_fill(mp.job[0], out, ldo, c1, c2, x, tlut, m, n, k, k1, k2);
+    int grid;
+    plan_launch(mp, nullptr, grid);
     int rc = zero_if_split(mp.job[0], m, stream);
     if (rc) return rc;
-    int grid;
-    finish_multi(mp, grid);
     return launch_tcq_gemv(mp, S, KV1, KV2, grid, stream);
 }
 
@@ -199,6 +209,7 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
     hipStream_t s = static_cast<hipStream_t>(stream);
     TcMultiParams mp{};
     mp.njobs = njobs;
+    int zeroed[kMaxJobs] = {0};
     for (int j = 0; j < njobs; j++) {
         const qpal_tcq_job &jb = jobs[j];
         int rc = tcq_check(jb.c1, jb.c2, jb.tlut, jb.m, jb.k, S, KV1, KV2, split);
@@ -207,13 +218,16 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         if (!aligned(jb.x, 8) || !aligned(jb.out, 4) || (jb.k % 4)) return QPAL_E_ALIGN;
         if (split == QPAL_SPLIT_NONE) tcq_fill(mp.job[j], jb.out, jb.m, jb.c1, nullptr, jb.x, jb.tlut, jb.m, n, jb.k, jb.k, 0);
         else tcq_fill(mp.job[j], jb.out, jb.m, jb.c1, jb.c2, jb.x, jb.tlut, jb.m, n, jb.k, jb.k / 2, jb.k / 2);
-        rc = zero_if_split(mp.job[j], jb.m, s, jb.out_zeroed);
-        if (rc) return rc;
+        zeroed[j] = jb.out_zeroed;
     }
     mp.zero = static_cast<u32x4 *>(prezero);
     mp.zero_chunks = (int)(prezero_bytes / 16);
     int grid;
-    finish_multi(mp, grid);
+    plan_launch(mp, zeroed, grid);
+    for (int j = 0; j < njobs; j++) {
+        int rc = zero_if_split(mp.job[j], jobs[j].m, s, jobs[j].out_zeroed);
+        if (rc) return rc;
+    }
     return launch_tcq_gemv(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, grid, s);
 }
 
@@ -260,8 +274,6 @@ static void lut_fill(TcParams &p, float *out, const void *qweight, const void *x
     p.nrows = m / 32;
     p.nsc1 = k / 32;
     p.st1 = (p.nsc1 + 3) / 4;
-    int grid;
-    gemv_geometry(p.nrows, p.st1, 0, p, grid);
     p.x_lds = x_fits_lds(n, k);
 }
 
@@ -288,18 +300,22 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
     hipStream_t s = static_cast<hipStream_t>(stream);
     TcMultiParams mp{};
     mp.njobs = njobs;
+    int zeroed[kMaxJobs] = {0};
     for (int j = 0; j < njobs; j++) {
         const qpal_lut_job &jb = jobs[j];
         int rc = lut_args_ok(jb.out, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k, bits, vec);
         if (rc) return rc;
         lut_fill(mp.job[j], jb.out, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k);
-        rc = zero_if_split(mp.job[j], jb.m, s, jb.out_zeroed);
-        if (rc) return rc;
+        zeroed[j] = jb.out_zeroed;
     }
     mp.zero = static_cast<u32x4 *>(prezero);
     mp.zero_chunks = (int)(prezero_bytes / 16);
     int grid;
-    finish_multi(mp, grid);
+    plan_launch(mp, zeroed, grid);
+    for (int j = 0; j < njobs; j++) {
+        int rc = zero_if_split(mp.job[j], jobs[j].m, s, jobs[j].out_zeroed);
+        if (rc) return rc;
+    }
     return launch_lut_tc_gemv(mp, bits, vec, grid, s);
 }
 

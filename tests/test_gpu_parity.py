@@ -240,7 +240,8 @@ def test_errors_are_exceptions(qp):
 
 
 def test_multi_job_launch_equals_single_launches(qp):
-    """q|k|v and gate|up as one multi-job launch give bit-identical results to one launch per linear."""
+    """q|k|v and gate|up as one multi-job launch agree with one launch per linear (the launch planner may
+    cut K differently, so the fp32 summation order - not the arithmetic - can differ: tolerance, not bits)."""
     k = 4096
     for qstr, ms in (("tcomb_6_7_0.5_none_0.9", [4096, 1024, 1024]), ("tcq_6_none_0.9", [14336, 14336]),
                      ("ldlq_2_8_none_1.0", [1024, 4096]), ("tcq_10_none_0.9", [1024, 2048, 512])):
@@ -250,7 +251,8 @@ def test_multi_job_launch_equals_single_launches(qp):
             x = torch.randn(n, k, generator=torch.Generator().manual_seed(n)).cuda()
             ys = qp.multi_gemv(layers, x)
             for layer, y in zip(layers, ys):
-                assert torch.equal(y, layer._gemv(x, n))
+                ref = layer._gemv(x, n)
+                assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
 
 
 def test_prezero_and_out_zeroed(qp, oracle):
