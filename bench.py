@@ -224,18 +224,20 @@ def main():
     def token():
         outs = []
         for groups in layers:
-            down_out = None
+            pre = {}  # group index -> output buffer zeroed by an earlier launch of this block
             for gi, grp in enumerate(groups):
                 x = xs[grp[0][1]]
                 mods = [m for m, _, _ in grp]
                 if args.launch == "multi" and gather is None:
-                    # projections of one input: one multi-job launch per codec.  The mlp-input launch also
-                    # zeroes down_proj's output so that its split-K needs no memset node of its own.
-                    if gi == 2 and not args.no_prezero:
-                        down_out = torch.empty((n, groups[3][0][0].out_features), dtype=torch.float32, device=device)
-                        outs += qp.multi_gemv(mods, x, prezero=down_out)
-                    elif gi == 3 and down_out is not None:
-                        outs += qp.multi_gemv(mods, x, outs=[down_out], outs_zeroed=True)
+                    # projections of one input: one multi-job launch per codec.  The attention-input / mlp-input
+                    # launches also zero the output of o_proj / down_proj, so that a split-K there (few rows:
+                    # half of the CUs would idle) needs no memset node of its own.
+                    nxt = gi + 1
+                    if gi in (0, 2) and not args.no_prezero and len(groups[nxt]) == 1:
+                        pre[nxt] = torch.empty((n, groups[nxt][0][0].out_features), dtype=torch.float32, device=device)
+                        outs += qp.multi_gemv(mods, x, prezero=pre[nxt])
+                    elif gi in pre:
+                        outs += qp.multi_gemv(mods, x, outs=[pre[gi]], outs_zeroed=True)
                     else:
                         outs += qp.multi_gemv(mods, x)
                     continue
