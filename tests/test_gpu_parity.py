@@ -272,3 +272,53 @@ def test_prezero_and_out_zeroed(qp, oracle):
     W = _oracle_weight(oracle, qstr, info, 4096, 14336)
     _check_gemv(y.cpu().numpy(), W, xd.numpy(), oracle)
     assert torch.equal(y, down._gemv(xd.cuda(), 1))
+
+
+RAGGED = [(32, 64), (32, 32), (96, 160), (160, 96), (32, 4096), (4096, 32), (64, 14336), (2048, 2560), (992, 1056)]
+
+
+@pytest.mark.parametrize("m,k", RAGGED)
+def test_ragged_shapes(qp, oracle, m, k):
+    """Partial steps (k/32 not a multiple of 4), single supertile rows, more waves than steps, tiny and long K."""
+    gen = torch.Generator().manual_seed(m * 7 + k)
+    cases = ["tcq_6_none_0.9", "tcq_7_none_0.9", "ldlq_1_4_none_1.0", "ldlq_2_9_none_1.0"]
+    if k % 64 == 0:
+        cases.append("tcomb_6_7_0.5_none_0.9")
+    for qstr in cases:
+        if "ldlq_2_9" in qstr and (9 * k) % 64:
+            continue
+        info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=m + k)
+        layer = qp.make_linear_from_info(qstr, info).cuda()
+        W = _oracle_weight(oracle, qstr, info, m, k)
+        assert np.array_equal(_bits(layer.get_weight()), W.view(np.uint16)), qstr
+        for n in (1, 2, 8):
+            x = torch.randn(n, k, generator=gen).half()
+            y = layer._gemv(x.cuda(), n)
+            _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle)
+
+
+def test_unsupported_shapes_raise(qp):
+    with pytest.raises(AttributeError):
+        qp.ops.get_op("decompress_gemm_tcq_48_1_64_9_6")      # m % 32
+    with pytest.raises(AttributeError):
+        qp.ops.get_op("decompress_gemm_tcq_64_0_64_9_6")      # n = 0
+    with pytest.raises(AttributeError):
+        qp.ops.get_op("decompress_gemm_tcq_combt_64_1_96_9_6_7")  # combt needs k % 64
+    op = qp.ops.get_op("decompress_gemm_tcq_64_2_64_9_6")
+    with pytest.raises(RuntimeError):   # x has the wrong batch
+        op(torch.zeros(16 * 48, dtype=torch.int16, device="cuda"), torch.zeros(1, 64, device="cuda"),
+           torch.zeros(512, 2, dtype=torch.float16, device="cuda"))
+
+
+@pytest.mark.parametrize("qstr,k,m", [("tcq_6_none_0.9", 8192, 57344), ("tcomb_6_7_0.5_none_0.9", 28672, 8192),
+                                      ("ldlq_2_8_none_1.0", 8192, 10240)])
+def test_llama70b_shapes(qp, oracle, qstr, k, m):
+    """Largest shapes of BASELINE.json configs[4] (70B: fused up|gate 57344x8192, down 8192x28672, qkv 10240x8192)."""
+    info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=1)
+    layer = qp.make_linear_from_info(qstr, info).cuda()
+    x = torch.randn(1, k, generator=torch.Generator().manual_seed(4)).half()
+    y = layer._gemv(x.cuda(), 1).cpu().numpy()
+    W = _oracle_weight(oracle, qstr, info, m, k)
+    _check_gemv(y, W, x.numpy(), oracle)
+    rows = slice(0, m, 997)   # dequant spot rows (bit-exact)
+    assert np.array_equal(_bits(layer.get_weight()[rows]), W[rows].view(np.uint16))
