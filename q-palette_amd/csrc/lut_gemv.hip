@@ -3,11 +3,14 @@
 
 namespace qpal {
 
-int launch_lut_tc_gemv(const TcMultiParams &p, int bits, int vec, int grid, hipStream_t stream) {
-#define QPAL_LUT(B_, V_)                                                                                \
-    if (bits == B_ && vec == V_) {                                                                      \
-        hipLaunchKernelGGL((tc_gemv_kernel<LutCodec<B_, V_>, void>), dim3(grid), dim3(1024), 0, stream, p); \
-        return (int)hipGetLastError();                                                                  \
+int launch_lut_tc_gemv(const TcMultiParams &p, int bits, int vec, int nbg, int grid, hipStream_t stream) {
+#define QPAL_LUT(B_, V_)                                                                                       \
+    if (bits == B_ && vec == V_) {                                                                             \
+        if (nbg == 1)                                                                                          \
+            hipLaunchKernelGGL((tc_gemv_kernel<LutCodec<B_, V_>, void, 1>), dim3(grid), dim3(1024), 0, stream, p); \
+        else                                                                                                   \
+            hipLaunchKernelGGL((tc_gemv_kernel<LutCodec<B_, V_>, void, 2>), dim3(grid), dim3(1024), 0, stream, p); \
+        return (int)hipGetLastError();                                                                         \
     }
 #include "lut_table.inc"
 #undef QPAL_LUT

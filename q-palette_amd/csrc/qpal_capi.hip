@@ -10,6 +10,8 @@ using namespace qpal;
 
 namespace {
 
+constexpr int kMaxBatch = 16;  // fused decode + GEMV / skinny GEMM: 2 MFMA column groups of 8 batch rows
+
 inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 // reference's S/KV table (lib/linear/__init__.py:166-172)
@@ -36,7 +38,7 @@ bool simt_ok(int bits, int vec) {
 // reduction buffer [16 waves][n][32] fp32 + x [n][k] fp16 must fit the kernel's LDS scratch
 int x_fits_lds(int n, int k) {
     static const int no_xlds = getenv("QPAL_NO_XLDS") != nullptr;
-    return !no_xlds && 16 * 32 * 4 * n + 2 * n * k + 64 <= kScratchBytes && (n * k) % 8 == 0;
+    return !no_xlds && n <= 8 && 16 * 32 * 4 * n + 2 * n * k + 64 <= kScratchBytes && (n * k) % 8 == 0;
 }
 
 int nb_of(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : 8; }
@@ -162,7 +164,7 @@ int tcq_gemv_one(float *out, long ldo, const void *c1, const void *c2, const voi
     plan_launch(mp, nullptr, grid);
     int rc = zero_if_split(mp.job[0], m, stream);
     if (rc) return rc;
-    return launch_tcq_gemv(mp, S, KV1, KV2, grid, stream);
+    return launch_tcq_gemv(mp, S, KV1, KV2, n <= 8 ? 1 : 2, grid, stream);
 }
 
 int tcq_check(const void *c1, const void *c2, const void *tlut, int m, int k, int S, int KV1, int KV2, int split) {
@@ -187,7 +189,7 @@ int qpal_tcq_gemv(float *out, const void *c1, const void *c2, const void *x, con
     int rc = tcq_check(c1, c2, tlut, m, k, S, KV1, KV2, split);
     if (rc) return rc;
     if (!out || !x) return QPAL_E_NULL;
-    if (n < 1 || n > 8) return QPAL_E_SHAPE;
+    if (n < 1 || n > kMaxBatch) return QPAL_E_SHAPE;
     if (!aligned(x, 8) || !aligned(out, 4) || (k % 4)) return QPAL_E_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (split == QPAL_SPLIT_NONE) return tcq_gemv_one(out, m, c1, nullptr, x, tlut, m, n, k, k, 0, S, KV1, 0, s);
@@ -205,7 +207,7 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
     if (njobs < 1 || njobs > kMaxJobs) return QPAL_E_SHAPE;
     if (prezero_bytes < 0 || prezero_bytes % 16 || (prezero_bytes && (!prezero || !aligned(prezero, 16)))) return QPAL_E_ALIGN;
     if (split == QPAL_SPLIT_ROWS) return QPAL_E_PARAM;  // the two row halves use different codecs: one call each
-    if (n < 1 || n > 8) return QPAL_E_SHAPE;
+    if (n < 1 || n > kMaxBatch) return QPAL_E_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     TcMultiParams mp{};
     mp.njobs = njobs;
@@ -228,7 +230,7 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         int rc = zero_if_split(mp.job[j], jobs[j].m, s, jobs[j].out_zeroed);
         if (rc) return rc;
     }
-    return launch_tcq_gemv(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, grid, s);
+    return launch_tcq_gemv(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, n <= 8 ? 1 : 2, grid, s);
 }
 
 int qpal_tcq_dequant(void *out_f16, const void *c1, const void *c2, const void *tlut, int m, int k, int S, int KV1,
@@ -280,7 +282,7 @@ static void lut_fill(TcParams &p, float *out, const void *qweight, const void *x
 static int lut_args_ok(const void *out, const void *qweight, const void *x, const void *lut, int m, int n, int k, int bits,
                        int vec) {
     if (!out || !qweight || !x || !lut) return QPAL_E_NULL;
-    if (m <= 0 || k <= 0 || m % 32 || k % 32 || n < 1 || n > 8) return QPAL_E_SHAPE;
+    if (m <= 0 || k <= 0 || m % 32 || k % 32 || n < 1 || n > kMaxBatch) return QPAL_E_SHAPE;
     if (!lut_tc_ok(bits, vec) || ((long)bits * k) % (32 * vec)) return QPAL_E_PARAM;
     if (!aligned(qweight, 4) || !aligned(x, 8) || !aligned(lut, 4) || !aligned(out, 4)) return QPAL_E_ALIGN;
     return QPAL_OK;
@@ -316,7 +318,7 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
         int rc = zero_if_split(mp.job[j], jobs[j].m, s, jobs[j].out_zeroed);
         if (rc) return rc;
     }
-    return launch_lut_tc_gemv(mp, bits, vec, grid, s);
+    return launch_lut_tc_gemv(mp, bits, vec, n <= 8 ? 1 : 2, grid, s);
 }
 
 int qpal_lut_tc_dequant(void *out_f16, const void *qweight, const void *lut, int m, int k, int bits, int vec,

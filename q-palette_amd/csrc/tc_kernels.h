@@ -253,53 +253,62 @@ __device__ __forceinline__ void load_step_w(const StreamView &sv, int step, int 
     load_words_nt<NW>(sv.base + ((long)sc * 16 + (lane & 15)) * NW, w);
 }
 
-// MFMA B operand of a step.  Lane (kb = lane>>4, c = lane&15) supplies, for batch row b = c>>1 and
+// Accumulators of one wave: NBG batch groups (8 batch rows each) x 4 row groups (msub*2 + jl).
+template <int NBG>
+struct Acc {
+    float4_t v[NBG][4];
+};
+
+// MFMA B operand of a step.  Lane (kb = lane>>4, c = lane&15) supplies, for batch row b = 8*grp + (c>>1) and
 // column half u = c&1, the 8 activations  x[b][col0 + 32*sc + 16*ksub + 8*jh + 4*u + 0..3], jh = 0,1
 // (order matches the A fragment: jh-major, then the reference lanes A|B, then the element of the pair).
-// XLDS: x was staged in LDS as [n][k] followed by a 64-byte zero pad (dead supertile columns of a partial
-// last step read the pad); otherwise x is read from global memory and dead lanes are zeroed by select.
-template <bool XLDS>
+// XLDS (batch <= 8 only): x was staged in LDS as [n][k] followed by a 64-byte zero pad (dead supertile
+// columns of a partial last step read the pad); otherwise x is read from global memory (L2) and dead lanes
+// are zeroed by select.
+template <bool XLDS, int NBG>
 __device__ __forceinline__ void load_step_x(const StreamView &sv, const uint16_t *xg, const uint16_t *xs, int k, int n,
-                                            int zero_off, int step, int lane, u32x4 (&xb)[2]) {
+                                            int zero_off, int step, int lane, u32x4 (&xb)[NBG][2]) {
     const int sc = step * 4 + (lane >> 4);
     const bool live = sc < sv.nsc;
     const int c = lane & 15;
-    int b = c >> 1;
-    b = b < n ? b : n - 1;
-    const int off = b * k + sv.col0 + sc * 32 + 4 * (c & 1);
-    if constexpr (XLDS) {
-        const uint16_t *row = xs + (live ? off : zero_off);
+    static_for<0, NBG>([&](auto gc) {
+        constexpr int grp = decltype(gc)::value;
+        int b = 8 * grp + (c >> 1);
+        b = b < n ? b : n - 1;
+        const int off = b * k + sv.col0 + sc * 32 + 4 * (c & 1);
+        if constexpr (XLDS) {
+            const uint16_t *row = xs + (live ? off : zero_off);
 #pragma unroll
-        for (int ksub = 0; ksub < 2; ksub++) {
-            const u32x2 lo = *reinterpret_cast<const u32x2 *>(row + 16 * ksub);
-            const u32x2 hi = *reinterpret_cast<const u32x2 *>(row + 16 * ksub + 8);
-            xb[ksub] = u32x4{lo.x, lo.y, hi.x, hi.y};
-        }
-    } else {
-        const uint16_t *row = xg + (live ? off : 0);
+            for (int ksub = 0; ksub < 2; ksub++) {
+                const u32x2 lo = *reinterpret_cast<const u32x2 *>(row + 16 * ksub);
+                const u32x2 hi = *reinterpret_cast<const u32x2 *>(row + 16 * ksub + 8);
+                xb[grp][ksub] = u32x4{lo.x, lo.y, hi.x, hi.y};
+            }
+        } else {
+            const uint16_t *row = xg + (live ? off : 0);
 #pragma unroll
-        for (int ksub = 0; ksub < 2; ksub++) {
-            const u32x2 lo = *reinterpret_cast<const u32x2 *>(row + 16 * ksub);
-            const u32x2 hi = *reinterpret_cast<const u32x2 *>(row + 16 * ksub + 8);
-            xb[ksub] = live ? u32x4{lo.x, lo.y, hi.x, hi.y} : u32x4{0u, 0u, 0u, 0u};
+            for (int ksub = 0; ksub < 2; ksub++) {
+                const u32x2 lo = *reinterpret_cast<const u32x2 *>(row + 16 * ksub);
+                const u32x2 hi = *reinterpret_cast<const u32x2 *>(row + 16 * ksub + 8);
+                xb[grp][ksub] = live ? u32x4{lo.x, lo.y, hi.x, hi.y} : u32x4{0u, 0u, 0u, 0u};
+            }
         }
-    }
+    });
 }
 
-// One step = 8 MFMAs (16x16x32 f16): per tile group (ksub, msub) the 8 decoded half2 of a lane form the
-// A fragments of two MFMAs (jl = 0, 1: tile rows p>>1 and (p>>1)+8).  MFMA row i = lane&15 = p is the
-// VIRTUAL row (tile row p>>1, column half u = p&1); MFMA column j = 2b+u; D[i][j] is a valid partial
-// product only where the two u agree.  acc[msub*2+jl] accumulates over ksub, steps and supertiles.
-template <class Codec>
+// One step = 8 MFMAs (16x16x32 f16) per batch group: per tile group (ksub, msub) the 8 decoded half2 of a
+// lane form the A fragments of two MFMAs (jl = 0, 1: tile rows p>>1 and (p>>1)+8).  MFMA row i = lane&15 = p
+// is the VIRTUAL row (tile row p>>1, column half u = p&1); MFMA column j = 2b+u; D[i][j] is a valid partial
+// product only where the two u agree.  acc.v[grp][msub*2+jl] accumulates over ksub, steps and supertiles.
+// The decode (all of the VALU work) is shared by the batch groups: batches 9..16 cost 8 more MFMAs per step.
+template <class Codec, int NBG>
 __device__ __forceinline__ void gemv_step(const uint32_t *lut, uint32_t laneoff, const uint32_t (&w)[Codec::NW],
-                                          const u32x4 (&xb)[2], float4_t &acc0, float4_t &acc1, float4_t &acc2,
-                                          float4_t &acc3) {
+                                          const u32x4 (&xb)[NBG][2], Acc<NBG> &acc) {
     static_for<0, 4>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         constexpr int ksub = g >> 1, msub = g & 1;
         uint32_t nh = 0u;
         if constexpr (Codec::kNeedsNext) nh = row16_next(Codec::template head<g>(w));
-        const half8_t bfrag = __builtin_bit_cast(half8_t, xb[ksub]);
         static_for<0, 2>([&](auto jc) {
             constexpr int jl = decltype(jc)::value;
             // fragment order (jh, isB): i = jl + 2*jh + 4*isB
@@ -308,54 +317,58 @@ __device__ __forceinline__ void gemv_step(const uint32_t *lut, uint32_t laneoff,
                           Codec::template pair<g, jl + 2>(lut, laneoff, w, nh),
                           Codec::template pair<g, jl + 6>(lut, laneoff, w, nh)};
             const half8_t afrag = __builtin_bit_cast(half8_t, a);
-            if constexpr (msub == 0 && jl == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc0, 0, 0, 0);
-            if constexpr (msub == 0 && jl == 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc1, 0, 0, 0);
-            if constexpr (msub == 1 && jl == 0) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc2, 0, 0, 0);
-            if constexpr (msub == 1 && jl == 1) acc3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc3, 0, 0, 0);
+            static_for<0, NBG>([&](auto bc) {
+                constexpr int grp = decltype(bc)::value;
+                acc.v[grp][msub * 2 + jl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                    afrag, __builtin_bit_cast(half8_t, xb[grp][ksub]), acc.v[grp][msub * 2 + jl], 0, 0, 0);
+            });
         });
     });
 }
 
 // steps [s0, s1) of one stream; `w` already holds step s0 (loaded before the codebook image was built).
 // Two register sets ping-pong (loop unrolled by 2) so the one-step-ahead prefetch costs no copies.
-template <class Codec, bool XLDS>
+template <class Codec, bool XLDS, int NBG>
 __device__ __forceinline__ void gemv_run(uint32_t (&w)[Codec::NW], const uint32_t *lut, uint32_t laneoff,
                                          const StreamView &sv, const uint16_t *xg, const uint16_t *xs, int k, int n,
-                                         int zero_off, int s0, int s1, int lane, float4_t &acc0, float4_t &acc1,
-                                         float4_t &acc2, float4_t &acc3) {
+                                         int zero_off, int s0, int s1, int lane, Acc<NBG> &acc) {
     uint32_t wb[Codec::NW];
     for (int s = s0; s < s1; s += 2) {
         {
             const int sn = s + 1 < s1 ? s + 1 : s;  // last step re-reads itself (L1 hit, unused)
             load_step_w<Codec::NW>(sv, sn, lane, wb);
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's decode (hipcc sinks it otherwise)
-            u32x4 xb[2];
-            load_step_x<XLDS>(sv, xg, xs, k, n, zero_off, s, lane, xb);
-            gemv_step<Codec>(lut, laneoff, w, xb, acc0, acc1, acc2, acc3);
+            u32x4 xb[NBG][2];
+            load_step_x<XLDS, NBG>(sv, xg, xs, k, n, zero_off, s, lane, xb);
+            gemv_step<Codec, NBG>(lut, laneoff, w, xb, acc);
         }
         if (s + 1 < s1) {
             const int sn = s + 2 < s1 ? s + 2 : s + 1;
             load_step_w<Codec::NW>(sv, sn, lane, w);
             __builtin_amdgcn_sched_barrier(0);
-            u32x4 xb[2];
-            load_step_x<XLDS>(sv, xg, xs, k, n, zero_off, s + 1, lane, xb);
-            gemv_step<Codec>(lut, laneoff, wb, xb, acc0, acc1, acc2, acc3);
+            u32x4 xb[NBG][2];
+            load_step_x<XLDS, NBG>(sv, xg, xs, k, n, zero_off, s + 1, lane, xb);
+            gemv_step<Codec, NBG>(lut, laneoff, wb, xb, acc);
         }
     }
 }
 
+// LDS beside the 64 KiB codebook image: reduction buffer [16 waves][n][32] fp32 (+ x for batch <= 8)
+template <int NBG>
+constexpr int scratch_bytes() { return NBG == 1 ? kScratchBytes : 16 * 32 * 4 * 8 * NBG; }
+
 // ------------------------------------------------------------------------------------------------
-// Fused decode + GEMV, 1 <= n <= 8.  1024 threads (16 waves, 4 per SIMD), one workgroup per CU
-// (LDS-bound).  C2 == void: single stream.  Otherwise combt (columns [0,col2) from c1 via C1, the rest
-// from c2 via C2); both codecs share one codebook image.  A wave's chunk of steps never straddles the two
-// streams.  When they fit beside the codebook image the activations are staged once per workgroup in LDS.
+// Fused decode + GEMV / skinny GEMM, 1 <= n <= 8*NBG.  1024 threads (16 waves, 4 per SIMD), one workgroup per
+// CU (LDS-bound).  C2 == void: single stream.  Otherwise combt (columns [0,col2) from c1 via C1, the rest from
+// c2 via C2); both codecs share one codebook image.  A wave's chunk of steps never straddles the two streams.
+// When they fit beside the codebook image (batch <= 8) the activations are staged once per workgroup in LDS.
 // All index arithmetic is shift/compare: the host passes the chunk partition (base/rem) precomputed.
-template <class C1, class C2>
+template <class C1, class C2, int NBG>
 __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
     constexpr bool TWO = !std::is_void_v<C2>;
     using CB = std::conditional_t<TWO, C2, C1>;
     __shared__ __attribute__((aligned(16))) uint32_t lut[C1::LDS_DWORDS];
-    __shared__ __attribute__((aligned(16))) unsigned char scratch[kScratchBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char scratch[scratch_bytes<NBG>()];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -398,6 +411,7 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
         const int wr = wave & (wpr - 1);      // this wave's K-chunk inside the row
         const int log2_rpw = 4 - p.log2_wpr;  // log2(rows per workgroup)
         const int zero_off = p.n * p.k;
+        const bool x_lds = NBG == 1 && p.x_lds;
         QPAL_STAMP(0);
 
         int rg = item, ks = 0;
@@ -418,14 +432,19 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
         const StreamView sv1{p.c1 + (long)(live ? sr : 0) * p.nsc1 * 16 * C1::NW, p.nsc1, 0};
         const StreamView sv2{TWO ? p.c2 + (long)(live ? sr : 0) * p.nsc2 * 16 * CB::NW : p.c1, TWO ? p.nsc2 : p.nsc1,
                              p.col2};
-        float4_t acc0{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+        Acc<NBG> acc;
+        static_for<0, NBG>([&](auto bc) {
+            static_for<0, 4>([&](auto ac) {
+                acc.v[decltype(bc)::value][decltype(ac)::value] = float4_t{0.f, 0.f, 0.f, 0.f};
+            });
+        });
 
         // first step's weights are in flight while x and the codebook image are (re)staged
         if (on2) load_step_w<CB::NW>(sv2, s0, lane, w.b);
         else load_step_w<C1::NW>(sv1, s0, lane, w.a);
         QPAL_STAMP(1);
-        if (p.tab != cur_tab || (p.x_lds && p.x != cur_x)) {  // workgroup-uniform
-            if (p.x_lds && p.x != cur_x) {
+        if (p.tab != cur_tab || (x_lds && p.x != cur_x)) {  // workgroup-uniform
+            if (x_lds && p.x != cur_x) {
                 const int total = p.n * p.k;  // multiple of 8 halves
                 for (int i = tid * 8; i < total + 32; i += 1024 * 8) {
                     u32x4 v{0u, 0u, 0u, 0u};
@@ -442,12 +461,17 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
             __syncthreads();
         }
         QPAL_STAMP(3);
-        if (p.x_lds) {
-            if (on2) gemv_run<CB, true>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc0, acc1, acc2, acc3);
-            else gemv_run<C1, true>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc0, acc1, acc2, acc3);
+        if constexpr (NBG == 1) {
+            if (x_lds) {
+                if (on2) gemv_run<CB, true, 1>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else gemv_run<C1, true, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+            } else {
+                if (on2) gemv_run<CB, false, 1>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else gemv_run<C1, false, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+            }
         } else {
-            if (on2) gemv_run<CB, false>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc0, acc1, acc2, acc3);
-            else gemv_run<C1, false>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc0, acc1, acc2, acc3);
+            if (on2) gemv_run<CB, false, NBG>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+            else gemv_run<C1, false, NBG>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
         }
         QPAL_STAMP(4);
 
@@ -455,23 +479,23 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
         // r&1 == u.  On even lanes (u = 0): own r = 0 / 2 plus the odd neighbour's r = 1 / 3 are the two
         // column halves of tile rows 2q and 2q+1.  (Odd lanes compute garbage that is never stored.)
         {
-            const int q = lane >> 4, cidx = lane & 15, b = cidx >> 1;
-            const bool writer = (cidx & 1) == 0 && b < p.n;
-            float *dst = red + ((wave * p.n + b) * 32) + 2 * q;
-            const float a00 = acc0[0] + __shfl_xor(acc0[1], 1, 64), a01 = acc0[2] + __shfl_xor(acc0[3], 1, 64);
-            const float a10 = acc1[0] + __shfl_xor(acc1[1], 1, 64), a11 = acc1[2] + __shfl_xor(acc1[3], 1, 64);
-            const float a20 = acc2[0] + __shfl_xor(acc2[1], 1, 64), a21 = acc2[2] + __shfl_xor(acc2[3], 1, 64);
-            const float a30 = acc3[0] + __shfl_xor(acc3[1], 1, 64), a31 = acc3[2] + __shfl_xor(acc3[3], 1, 64);
-            if (writer) {  // rows 16*msub + 8*jl + 2q + {0,1}
-                dst[0] = a00;
-                dst[1] = a01;
-                dst[8] = a10;
-                dst[9] = a11;
-                dst[16] = a20;
-                dst[17] = a21;
-                dst[24] = a30;
-                dst[25] = a31;
-            }
+            const int q = lane >> 4, cidx = lane & 15;
+            static_for<0, NBG>([&](auto bc) {
+                constexpr int grp = decltype(bc)::value;
+                const int b = 8 * grp + (cidx >> 1);
+                const bool writer = (cidx & 1) == 0 && b < p.n;
+                float *dst = red + ((wave * p.n + (b < p.n ? b : 0)) * 32) + 2 * q;
+                static_for<0, 4>([&](auto ac) {  // rows 16*msub + 8*jl + 2q + {0,1}
+                    constexpr int a = decltype(ac)::value;
+                    const float4_t d = acc.v[grp][a];
+                    const float v0 = d[0] + __shfl_xor(d[1], 1, 64);
+                    const float v1 = d[2] + __shfl_xor(d[3], 1, 64);
+                    if (writer) {
+                        dst[8 * a] = v0;
+                        dst[8 * a + 1] = v1;
+                    }
+                });
+            });
         }
         QPAL_STAMP(5);
         __syncthreads();

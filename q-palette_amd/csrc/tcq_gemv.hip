@@ -6,7 +6,7 @@
 
 namespace qpal {
 
-template <int S, int KV1, int KV2>
+template <int S, int KV1, int KV2, int NBG>
 static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
     [[maybe_unused]] const TcParams &p = mp.job[0];
     using C1 = TcqCodec<S, KV1>;
@@ -25,7 +25,7 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
         hipMalloc(&d, nb);
         hipMemset(d, 0, nb);
         q.dbg = d;
-        for (int rep = 0; rep < 3; rep++) { TcMultiParams mq = mp; mq.job[0] = q; hipLaunchKernelGGL((tc_gemv_kernel<C1, C2>), dim3(grid), dim3(1024), 0, stream, mq); }
+        for (int rep = 0; rep < 3; rep++) { TcMultiParams mq = mp; mq.job[0] = q; hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG>), dim3(grid), dim3(1024), 0, stream, mq); }
         hipDeviceSynchronize();
         unsigned long long *h = (unsigned long long *)malloc(nb);
         hipMemcpy(h, d, nb, hipMemcpyDeviceToHost);
@@ -45,13 +45,14 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
         hipFree(d);
     }
 #endif
-    hipLaunchKernelGGL((tc_gemv_kernel<C1, C2>), dim3(grid), dim3(1024), 0, stream, mp);
+    hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG>), dim3(grid), dim3(1024), 0, stream, mp);
     return (int)hipGetLastError();
 }
 
-int launch_tcq_gemv(const TcMultiParams &p, int S, int KV1, int KV2, int grid, hipStream_t stream) {
-#define QPAL_TCQ(S_, A_, B_) \
-    if (S == S_ && KV1 == A_ && KV2 == B_) return launch_one<S_, A_, B_>(p, grid, stream);
+int launch_tcq_gemv(const TcMultiParams &p, int S, int KV1, int KV2, int nbg, int grid, hipStream_t stream) {
+#define QPAL_TCQ(S_, A_, B_)                                                                 \
+    if (S == S_ && KV1 == A_ && KV2 == B_)                                                   \
+        return nbg == 1 ? launch_one<S_, A_, B_, 1>(p, grid, stream) : launch_one<S_, A_, B_, 2>(p, grid, stream);
 #include "tcq_table.inc"
 #undef QPAL_TCQ
     return QPAL_E_PARAM;

@@ -87,7 +87,7 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None):
 
     x2 = x.reshape(-1, layers[0].in_features)
     n = x2.shape[0]
-    if n > 8:
+    if n > 16:
         return [l(x2) for l in layers]
     results = [None] * len(layers)
     for idxs in launch_groups(layers):
@@ -109,7 +109,7 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None):
                                        first.vec_sz, **extra)
             prezero = None
         else:
-            ys = [first._gemv(x2, n)]
+            ys = [first._gemv(x2, n) if n <= first.max_fused_batch else first(x2)]
             if o is not None:
                 o[0].copy_(ys[0])
                 ys = o

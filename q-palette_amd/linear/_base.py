@@ -11,6 +11,7 @@ GEMV_MAX_BATCH = 8  # reference: `if bs <= 8` in every forward (e.g. lib/linear/
 class PackedLinearBase(nn.Module):
     in_features: int
     out_features: int
+    max_fused_batch = GEMV_MAX_BATCH  # tensor-core-order families raise this to 16 (second MFMA column group)
 
     def _gemv(self, x, bs):  # -> [bs, m] (fp32 or fp16)
         raise NotImplementedError
@@ -21,7 +22,7 @@ class PackedLinearBase(nn.Module):
     def forward(self, inp, **kwargs):
         x = inp.reshape(-1, self.in_features)
         bs = x.shape[0]
-        if bs <= GEMV_MAX_BATCH:
+        if bs <= self.max_fused_batch:
             y = self._gemv(x, bs)
         else:
             with torch.no_grad():

@@ -42,6 +42,7 @@ class _VQBase(PackedLinearBase):
 
 class VQLinearPackTensorCore(_VQBase):
     """Codes stored in mma-tile order (quant_op.py:101-162); fp32 GEMV output."""
+    max_fused_batch = 16
 
     def __init__(self, in_features, out_features, lut_bits, vec_sz=2, bias=False, dtype=torch.half, device=None):
         super().__init__(in_features, out_features, lut_bits, vec_sz, bias, dtype, device)

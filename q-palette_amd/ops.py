@@ -16,7 +16,8 @@ Name grammar (reference file:line):
   decompress_{bits}_{vtype}                                     :94-117
   sq_pack_gemm_simt / sq_pack_dequant_simt / sq_pack_gemm_inplace_simt   :349-378
   vq_pack_gemm_simt_{maxm}_{vec}_{bits} ; vq_pack_dequant_simt_{vec}_{bits}   :383-420
-Unlike the reference, any 1 <= n <= 8 and any m % 32 == 0, k % 32 == 0 is accepted at run time.
+Unlike the reference, any 1 <= n <= 16 (tensor-core-order families; SIMT: n <= 8) and any m % 32 == 0,
+k % 32 == 0 is accepted at run time.
 """
 import re
 import threading
@@ -238,7 +239,7 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
     outs: write into these tensors (outs_zeroed: they are all zeros already); prezero: a tensor this launch
     also zeroes for a later split-K launch on the same stream."""
     n, k = x.shape
-    _chk(1 <= n <= 8, "batch size must be in 1..8")
+    _chk(1 <= n <= MAX_FUSED_BATCH, "batch size must be in 1..16")
     xh = _dev(x.to(torch.float16), "x")
     jobs = (nat.TcqJob * len(streams))()
     results, keep = [], [xh]
@@ -273,7 +274,7 @@ def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezer
     """Several VQ/SQ (tensor-core packing) GEMVs of one codec and one input in ONE launch.
     layers: list of (qweight, lut, m); x: [n, k].  outs / outs_zeroed / prezero as in tcq_gemv_multi."""
     n, k = x.shape
-    _chk(1 <= n <= 8, "batch size must be in 1..8")
+    _chk(1 <= n <= MAX_FUSED_BATCH, "batch size must be in 1..16")
     xh = _dev(x.to(torch.float16), "x")
     jobs = (nat.LutJob * len(layers))()
     results, keep = [], [xh]
@@ -336,8 +337,11 @@ def _tcq_ok(S, KV):
     return S in _TCQ_KV and KV in _TCQ_KV[S]
 
 
+MAX_FUSED_BATCH = 16  # the reference's fused ops stop at 8; here 9..16 run as a second MFMA column group
+
+
 def _shape_ok(m, n, k):
-    return m % 32 == 0 and k % 32 == 0 and 1 <= n <= 8
+    return m % 32 == 0 and k % 32 == 0 and 1 <= n <= MAX_FUSED_BATCH
 
 
 def ensure_op(name):

@@ -322,3 +322,19 @@ def test_llama70b_shapes(qp, oracle, qstr, k, m):
     _check_gemv(y, W, x.numpy(), oracle)
     rows = slice(0, m, 997)   # dequant spot rows (bit-exact)
     assert np.array_equal(_bits(layer.get_weight()[rows]), W[rows].view(np.uint16))
+
+
+@pytest.mark.parametrize("qstr,k,m", [("tcomb_6_7_0.5_none_0.9", 4096, 4096), ("tcq_8_none_0.9", 4096, 1024),
+                                      ("ldlq_1_4_none_1.0", 4096, 2048), ("ldlq_2_12_none_1.0", 4096, 1024),
+                                      ("tcq_6_none_0.9", 14336, 4096)])
+def test_fused_skinny_gemm_batch_9_to_16(qp, oracle, qstr, k, m):
+    """Batches 9..16 run fused (second MFMA column group) instead of dequant + GEMM."""
+    info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=5)
+    layer = qp.make_linear_from_info(qstr, info).cuda()
+    W = _oracle_weight(oracle, qstr, info, m, k)
+    gen = torch.Generator().manual_seed(9)
+    for n in (9, 13, 16):
+        x = torch.randn(n, k, generator=gen).half()
+        y = layer(x.cuda().float())
+        assert y.dtype == torch.float32 and tuple(y.shape) == (n, m)
+        _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle)
