@@ -14,7 +14,7 @@
  *   TCQ codebook  fp16   [2^S][2]                   lib/linear/tcq_linear.py:37-40
  *   LUT-TC        int32  [m][bits*k/32/vec], fp16 lut [2^bits][vec]   lib/linear/vq_linear.py:15-23
  *   LUT-SIMT      uint32 [m][bits*k/32/vec]         lib/quantizer/pack_op.py:288-335, quant_op.py:69-78
- *   x             fp16   [n][k] row-major, 1 <= n <= 8
+ *   x             fp16   [n][k] row-major, 1 <= n <= 16 (tensor-core-order families), 1 <= n <= 8 (SIMT)
  */
 #ifndef QPAL_H
 #define QPAL_H
@@ -25,10 +25,10 @@
 extern "C" {
 #endif
 
-#define QPAL_VERSION 100
+#define QPAL_VERSION 110
 
 #define QPAL_OK 0
-#define QPAL_E_SHAPE (-1)   /* m, k, n outside the supported set (m%32, k%32, 1<=n<=8 ...) */
+#define QPAL_E_SHAPE (-1)   /* m, k, n outside the supported set (m%32, k%32, 1<=n<=16 ...) */
 #define QPAL_E_PARAM (-2)   /* S / KV / bits / vec / split combination not supported        */
 #define QPAL_E_NULL (-3)    /* required pointer is NULL                                      */
 #define QPAL_E_ALIGN (-4)   /* pointer not aligned to the format's natural alignment         */
@@ -58,6 +58,12 @@ typedef struct qpal_tcq_job {
     int m, k;
     int out_zeroed;    /* 1: the caller guarantees out is all zeros (e.g. pre-zeroed by an earlier launch, below):
                           a split-K job then needs no memset node of its own */
+    const void *wscale; /* fp16 [m] or NULL: fused epilogue out[b][r] = acc * wscale[r] * oscale — the
+                          `* Wscale * scale` that follows every quantized linear in the reference's incoherent
+                          wrappers (lib/linear/incoherent_linear.py:83-99, 107, 327-337, 496-503) */
+    float oscale;      /* 0 is read as 1 */
+    long ldo;          /* row stride of out in floats, >= m; 0 is read as m.  Lets q|k|v or up|gate write the
+                          column blocks of one [n][sum m] buffer */
 } qpal_tcq_job;
 /* prezero/prezero_bytes (may be NULL/0): a buffer this launch also fills with zeros, for a LATER launch on the
  * same stream that accumulates into it with atomics (split-K of a few-rows x long-K layer such as down_proj).
@@ -83,6 +89,9 @@ typedef struct qpal_lut_job {
     const void *lut;      /* fp16 [2^bits][vec] */
     int m, k;
     int out_zeroed;       /* as in qpal_tcq_job */
+    const void *wscale;   /* as in qpal_tcq_job */
+    float oscale;
+    long ldo;
 } qpal_lut_job;
 int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits, int vec, void *prezero,
                            long prezero_bytes, void *stream);
@@ -104,6 +113,25 @@ int qpal_lut_simt_dequant(void *out_f16, const void *qweight, const void *lut,
  * VQLinearPackSIMT.gen_layer_from_info, lib/linear/vq_linear.py:175-188 ->
  * lib/quantizer/quant_op.py:246-257).  vec in {1,2}.  dst: uint32 [m][bits*k/32/vec], zeroed by the call. */
 int qpal_tc_to_simt(void *dst_simt, const void *src_tc, int m, int k, int bits, int vec, void *stream);
+
+/* Incoherence rotation either side of a quantized linear, one launch:
+ *   out[r][blk] = fp16( hadK (x) H_P applied to (f(in)[r][blk] * su) / sqrt(hd) * post_scale [* sv] )
+ * for every block of hd = K * 2^p consecutive elements of every row (hd == n: whole-vector transform).
+ * Replaces matmul_hadU_cuda (lib/utils/matmul_had.py:137-148: third-party fast_hadamard_transform + hadK
+ * matmul) and matmul_hadU_head_cuda (:95-110) plus the elementwise ops around them in
+ * lib/linear/incoherent_linear.py:81, 106, 325-337 (incl. act_fn(gate) * up), 488-503.
+ *   in_mode   QPAL_IN_F16: fp16 [rows][n];  QPAL_IN_F32: fp32 [rows][n] (rounded to fp16 first, the reference's
+ *             .half());  QPAL_IN_SWIGLU_F32: fp32 [rows][2n] = up | gate, f = silu(gate) * up
+ *   su, sv    fp16 [n] element-wise pre / post multipliers or NULL (SU sign vector; SV * scale)
+ *   hadk      fp16 [K][K] row-major, entries +-1, applied as given (pass the transpose for had_left_T); NULL if K == 1
+ *   round_mid 1: fp16 between the butterflies and the hadK product (matmul_hadU_cuda's fp16 pipeline);
+ *             0: fp32-grade throughout (matmul_hadU_head_cuda's float path)
+ * hd * 4 bytes must fit the 160 KiB LDS (hd <= 40960); K > 1 needs hd / K >= 16.                          */
+#define QPAL_IN_F16 0
+#define QPAL_IN_F32 1
+#define QPAL_IN_SWIGLU_F32 2
+int qpal_hadamard(void *out_f16, const void *in, const void *su, const void *sv, const void *hadk,
+                  int rows, int n, int hd, int K, int in_mode, int round_mid, float post_scale, void *stream);
 
 const char *qpal_error_string(int code);
 int qpal_version(void);

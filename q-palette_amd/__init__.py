@@ -7,6 +7,8 @@ Layout:
   linear/          nn.Module mirror of lib/linear/{tcq,comb,vq}_linear.py
   mem_op.py        quantizer-string grammar, Llama layer shapes, synthetic packed weights
                    (lib/utils/mem_op.py:2-307)
+  hadamard.py      get_hadK (generated Paley factors), matmul_hadU*_cuda, the one-launch `rotate` (lib/utils/matmul_had.py)
+  linear/incoherent_linear.py  IncoherentLinear / IncoherentMLP / IncoherentSdpaAttention (lib/linear/incoherent_linear.py)
   shard.py         row-sharding of packed layers across GPUs (torch.distributed / RCCL)
 
 There is deliberately no CPU implementation here: the CPU restatement lives in /oracle and is test
@@ -16,7 +18,12 @@ from . import _native  # noqa: F401
 from . import ops  # noqa: F401
 from . import mem_op  # noqa: F401
 from . import shard  # noqa: F401
+from . import hadamard  # noqa: F401
 from .linear import (  # noqa: F401
+    IncoherentLinear,
+    IncoherentMLP,
+    IncoherentSdpaAttention,
+    make_linear,
     CombLinearTCQ,
     CombtLinearTCQ,
     QTIPLinearTCQ,

@@ -12,18 +12,19 @@ _lib = None
 
 QPAL_SPLIT_NONE, QPAL_SPLIT_ROWS, QPAL_SPLIT_COLS = 0, 1, 2
 
-_P, _I = ctypes.c_void_p, ctypes.c_int
+_P, _I, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 
 
 class TcqJob(ctypes.Structure):
     """qpal_tcq_job (include/qpal.h)"""
     _fields_ = [("out", _P), ("c1", _P), ("c2", _P), ("x", _P), ("tlut", _P), ("m", _I), ("k", _I),
-                ("out_zeroed", _I)]
+                ("out_zeroed", _I), ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long)]
 
 
 class LutJob(ctypes.Structure):
     """qpal_lut_job (include/qpal.h)"""
-    _fields_ = [("out", _P), ("qweight", _P), ("x", _P), ("lut", _P), ("m", _I), ("k", _I), ("out_zeroed", _I)]
+    _fields_ = [("out", _P), ("qweight", _P), ("x", _P), ("lut", _P), ("m", _I), ("k", _I), ("out_zeroed", _I),
+                ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long)]
 
 
 _SIGNATURES = {
@@ -36,6 +37,7 @@ _SIGNATURES = {
     "qpal_lut_simt_gemv": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "qpal_lut_simt_dequant": [_P, _P, _P, _I, _I, _I, _I, _P],
     "qpal_tc_to_simt": [_P, _P, _I, _I, _I, _I, _P],
+    "qpal_hadamard": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
 }
 
 

@@ -126,8 +126,10 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid) {
 
 // fills one job's parameters + geometry; returns its item count through p.nitems
 void tcq_fill(TcParams &p, float *out, long ldo, const void *c1, const void *c2, const void *x, const void *tlut, int m,
-              int n, int k, int k1, int k2) {
+              int n, int k, int k1, int k2, const void *wscale = nullptr, float oscale = 1.0f) {
     p = TcParams{};
+    p.wscale = static_cast<const uint16_t *>(wscale);
+    p.oscale = oscale == 0.0f ? 1.0f : oscale;
     p.out = out;
     p.ldo = ldo;
     p.c1 = static_cast<const uint32_t *>(c1);
@@ -218,8 +220,14 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         if (rc) return rc;
         if (!jb.out || !jb.x) return QPAL_E_NULL;
         if (!aligned(jb.x, 8) || !aligned(jb.out, 4) || (jb.k % 4)) return QPAL_E_ALIGN;
-        if (split == QPAL_SPLIT_NONE) tcq_fill(mp.job[j], jb.out, jb.m, jb.c1, nullptr, jb.x, jb.tlut, jb.m, n, jb.k, jb.k, 0);
-        else tcq_fill(mp.job[j], jb.out, jb.m, jb.c1, jb.c2, jb.x, jb.tlut, jb.m, n, jb.k, jb.k / 2, jb.k / 2);
+        if (jb.wscale && !aligned(jb.wscale, 2)) return QPAL_E_ALIGN;
+        if (jb.ldo != 0 && jb.ldo < jb.m) return QPAL_E_SHAPE;
+        const long ldo = jb.ldo ? jb.ldo : jb.m;
+        if (split == QPAL_SPLIT_NONE)
+            tcq_fill(mp.job[j], jb.out, ldo, jb.c1, nullptr, jb.x, jb.tlut, jb.m, n, jb.k, jb.k, 0, jb.wscale, jb.oscale);
+        else
+            tcq_fill(mp.job[j], jb.out, ldo, jb.c1, jb.c2, jb.x, jb.tlut, jb.m, n, jb.k, jb.k / 2, jb.k / 2, jb.wscale,
+                     jb.oscale);
         zeroed[j] = jb.out_zeroed;
     }
     mp.zero = static_cast<u32x4 *>(prezero);
@@ -264,10 +272,13 @@ int qpal_tcq_dequant(void *out_f16, const void *c1, const void *c2, const void *
     return one(w + (size_t)(m / 2) * k, c2, nullptr, m / 2, k, 0, KV2, 0);
 }
 
-static void lut_fill(TcParams &p, float *out, const void *qweight, const void *x, const void *lut, int m, int n, int k) {
+static void lut_fill(TcParams &p, float *out, long ldo, const void *qweight, const void *x, const void *lut, int m, int n,
+                     int k, const void *wscale, float oscale) {
     p = TcParams{};
+    p.wscale = static_cast<const uint16_t *>(wscale);
+    p.oscale = oscale == 0.0f ? 1.0f : oscale;
     p.out = out;
-    p.ldo = m;
+    p.ldo = ldo;
     p.c1 = static_cast<const uint32_t *>(qweight);
     p.x = static_cast<const uint16_t *>(x);
     p.tab = lut;
@@ -290,7 +301,7 @@ static int lut_args_ok(const void *out, const void *qweight, const void *x, cons
 
 int qpal_lut_tc_gemv(float *out, const void *qweight, const void *x, const void *lut, int m, int n, int k, int bits,
                      int vec, void *stream) {
-    qpal_lut_job job{out, qweight, x, lut, m, k, 0};
+    qpal_lut_job job{out, qweight, x, lut, m, k, 0, nullptr, 1.0f, 0};
     return qpal_lut_tc_gemv_multi(&job, 1, n, bits, vec, nullptr, 0, stream);
 }
 
@@ -307,7 +318,9 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
         const qpal_lut_job &jb = jobs[j];
         int rc = lut_args_ok(jb.out, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k, bits, vec);
         if (rc) return rc;
-        lut_fill(mp.job[j], jb.out, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k);
+        if (jb.wscale && !aligned(jb.wscale, 2)) return QPAL_E_ALIGN;
+        if (jb.ldo != 0 && jb.ldo < jb.m) return QPAL_E_SHAPE;
+        lut_fill(mp.job[j], jb.out, jb.ldo ? jb.ldo : jb.m, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k, jb.wscale, jb.oscale);
         zeroed[j] = jb.out_zeroed;
     }
     mp.zero = static_cast<u32x4 *>(prezero);
@@ -381,7 +394,7 @@ int qpal_tc_to_simt(void *dst_simt, const void *src_tc, int m, int k, int bits, 
 const char *qpal_error_string(int code) {
     switch (code) {
         case QPAL_OK: return "ok";
-        case QPAL_E_SHAPE: return "unsupported shape (need m%32==0, k%32==0, 1<=n<=8)";
+        case QPAL_E_SHAPE: return "unsupported shape (need m%32==0, k%32==0, 1<=n<=16; see include/qpal.h)";
         case QPAL_E_PARAM: return "unsupported quantizer parameters (S/KV/bits/vec/split)";
         case QPAL_E_NULL: return "null pointer";
         case QPAL_E_ALIGN: return "misaligned pointer";

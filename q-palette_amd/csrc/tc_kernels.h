@@ -52,6 +52,8 @@ struct TcParams {
     int x_lds;          // 1: stage x[n][k] in LDS (fits beside the codebook image)
     int base1, rem1;    // stream 1: st1 = nc1*base1 + rem1 (first rem1 chunks get one more step)
     int base2, rem2;    // stream 2: st2 = (nchunk-nc1)*base2 + rem2
+    const uint16_t *wscale;  // gemv epilogue: fp16 [m] per-output-row scale or null
+    float oscale;            // gemv epilogue: out = acc * wscale[row] * oscale
     unsigned long long *dbg;  // QPAL_STAMPS diagnostic builds only: per-wave s_memtime stamps
 };
 
@@ -504,10 +506,13 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
             const int r = tid & 31, rl = tid >> 5;
             const int srow = (rg << log2_rpw) + rl;
             if (srow < p.nrows) {
+                float osc = p.oscale;  // the incoherent wrappers' `* Wscale * scale`, fused
+                if (p.wscale) osc *= (float)__builtin_bit_cast(_Float16, p.wscale[srow * 32 + r]);
                 for (int b = 0; b < p.n; b++) {
                     float v = 0.f;
                     for (int qq = 0; qq < wpr; qq++) v += red[(((rl << p.log2_wpr) + qq) * p.n + b) * 32 + r];
                     float *dst = p.out + (long)b * p.ldo + (long)srow * 32 + r;
+                    v *= osc;
                     if (p.sk == 1) *dst = v;
                     else atomicAdd(dst, v);
                 }

@@ -74,7 +74,7 @@ def launch_groups(layers):
     return out
 
 
-def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None):
+def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=None, oscale=1.0):
     """y_i = layers[i](x) for several quantized linears that share the input, batch <= 8.  Layers of one
     kind and codec (e.g. q|k|v or gate|up of one block) go out as ONE kernel launch per codec
     (C-ABI qpal_*_gemv_multi); anything else is one launch per layer.  Returns fp32/fp16 [n, m_i] tensors in
@@ -82,7 +82,9 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None):
 
     outs: fp32 [n, m_i] tensors to write into (outs_zeroed: they hold zeros, so a split-K layer needs no
     memset of its own); prezero: a tensor the first multi-job launch also zeroes — the way a decode block
-    prepares down_proj's output during the gate|up launch."""
+    prepares down_proj's output during the gate|up launch.
+    wscales (fp16 [m_i] vectors) / oscale: y_i = layers[i](x) * wscales[i] * oscale, fused into the GEMV epilogue for
+    the tensor-core-order families (the `* Wscale * scale` of the incoherent wrappers)."""
     from .. import ops
 
     x2 = x.reshape(-1, layers[0].in_features)
@@ -95,7 +97,8 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None):
         kind = _codec_key(first)[0]
         grp = [layers[i] for i in idxs]
         o = [outs[i] for i in idxs] if outs is not None else None
-        extra = dict(outs=o, outs_zeroed=outs_zeroed, prezero=prezero)
+        ws = [wscales[i] for i in idxs] if wscales is not None else None
+        extra = dict(outs=o, outs_zeroed=outs_zeroed, prezero=prezero, wscales=ws, oscale=oscale)
         if kind == "tcq":
             ys = ops.tcq_gemv_multi([(l.trellis, None, l.tlut, l.out_features) for l in grp], x2, first.tlut_bits,
                                     first.KV, **extra)
@@ -110,6 +113,10 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None):
             prezero = None
         else:
             ys = [first._gemv(x2, n) if n <= first.max_fused_batch else first(x2)]
+            if ws is not None and ws[0] is not None:
+                ys = [ys[0].float() * ws[0].float() * oscale]
+            elif oscale != 1.0:
+                ys = [ys[0].float() * oscale]
             if o is not None:
                 o[0].copy_(ys[0])
                 ys = o
@@ -120,5 +127,7 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None):
     return results
 
 
-__all__ = ["multi_gemv", "launch_groups", "share_codebooks","QTIPLinearTCQ", "CombLinearTCQ", "CombtLinearTCQ", "VQLinearPackTensorCore", "VQLinearPackSIMT",
+from .incoherent_linear import IncoherentLinear, IncoherentMLP, IncoherentSdpaAttention, make_linear  # noqa: E402
+
+__all__ = ["IncoherentLinear", "IncoherentMLP", "IncoherentSdpaAttention", "make_linear", "multi_gemv", "launch_groups", "share_codebooks","QTIPLinearTCQ", "CombLinearTCQ", "CombtLinearTCQ", "VQLinearPackTensorCore", "VQLinearPackSIMT",
            "linear_class_for", "make_linear_from_info"]

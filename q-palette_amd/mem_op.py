@@ -35,6 +35,8 @@ LAYER_INFO = {
     "3_70b": _llama(80, 8192, 1024, 28672),
 }
 LINEAR_KEYS = list(_LINEAR_KEYS)
+# HF model id -> key of LAYER_INFO (reference lib/config.py:1-5)
+MODEL_KEYS = {"meta-llama/Llama-3.1-8B": "3_8b", "meta-llama/Llama-3.2-1B": "3_1b", "meta-llama/Llama-3.2-3B": "3_3b"}
 
 
 def get_layer_info(model_key):

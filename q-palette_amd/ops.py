@@ -233,11 +233,38 @@ def _prezero_args(prezero):
     return prezero.data_ptr(), prezero.numel() * prezero.element_size()
 
 
-def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=False, prezero=None):
+def _out_arg(outs, j, n, m, device):
+    """fp32 [n, m] destination: a fresh tensor, or the caller's (row stride >= m allowed: a column block of a
+    wider [n, sum m] buffer)."""
+    if outs is None:
+        return torch.empty((n, m), dtype=torch.float32, device=device)
+    out = outs[j]
+    _chk(out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == (n, m) and out.stride(1) == 1
+         and (n == 1 or out.stride(0) >= m),
+         f"outs[{j}] must be an fp32 CUDA tensor of shape ({n}, {m}) with unit column stride")
+    return out
+
+
+def _ldo(out, n, m):
+    return out.stride(0) if n > 1 else m
+
+
+def _wscale_arg(wscales, j, m):
+    if wscales is None or wscales[j] is None:
+        return None
+    w = wscales[j]
+    _chk(w.is_cuda and w.is_contiguous() and w.dtype == torch.float16 and w.numel() == m,
+         f"wscales[{j}] must be a contiguous fp16 CUDA vector of {m} elements")
+    return w.data_ptr()
+
+
+def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=False, prezero=None, wscales=None,
+                   oscale=1.0):
     """Several TCQ GEMVs of one codec and one input in ONE launch (C-ABI qpal_tcq_gemv_multi).
     streams: list of (c1, c2_or_None, tlut, m); x: [n, k].  Returns the list of fp32 [n, m] outputs.
     outs: write into these tensors (outs_zeroed: they are all zeros already); prezero: a tensor this launch
-    also zeroes for a later split-K launch on the same stream."""
+    also zeroes for a later split-K launch on the same stream.
+    wscales / oscale: fused epilogue out = acc * wscales[j][row] * oscale (the incoherent wrappers' Wscale * scale)."""
     n, k = x.shape
     _chk(1 <= n <= MAX_FUSED_BATCH, "batch size must be in 1..16")
     xh = _dev(x.to(torch.float16), "x")
@@ -253,14 +280,10 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
             c2 = _dev(c2, "compressed2")
             _tcq_stream_ok(c1, m, k // 2, KV1, "compressed1")
             _tcq_stream_ok(c2, m, k // 2, KV2, "compressed2")
-        if outs is not None:
-            out = outs[j]
-            _chk(out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (n, m),
-                 f"outs[{j}] must be a contiguous fp32 CUDA tensor of shape ({n}, {m})")
-        else:
-            out = torch.empty((n, m), dtype=torch.float32, device=x.device)
+        out = _out_arg(outs, j, n, m, x.device)
         jobs[j] = nat.TcqJob(out.data_ptr(), c1.data_ptr(), c2.data_ptr() if c2 is not None else None,
-                             xh.data_ptr(), tl.data_ptr(), m, k, 1 if (outs is not None and outs_zeroed) else 0)
+                             xh.data_ptr(), tl.data_ptr(), m, k, 1 if (outs is not None and outs_zeroed) else 0,
+                             _wscale_arg(wscales, j, m), float(oscale), _ldo(out, n, m))
         results.append(out)
         keep += [c1, c2, tl]
     zp, zb = _prezero_args(prezero)
@@ -270,7 +293,7 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
     return results
 
 
-def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezero=None):
+def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezero=None, wscales=None, oscale=1.0):
     """Several VQ/SQ (tensor-core packing) GEMVs of one codec and one input in ONE launch.
     layers: list of (qweight, lut, m); x: [n, k].  outs / outs_zeroed / prezero as in tcq_gemv_multi."""
     n, k = x.shape
@@ -280,14 +303,10 @@ def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezer
     results, keep = [], [xh]
     for j, (q, lut, m) in enumerate(layers):
         q, cb = _lut_args(q, lut, m, k, bits, vec)
-        if outs is not None:
-            out = outs[j]
-            _chk(out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (n, m),
-                 f"outs[{j}] must be a contiguous fp32 CUDA tensor of shape ({n}, {m})")
-        else:
-            out = torch.empty((n, m), dtype=torch.float32, device=x.device)
+        out = _out_arg(outs, j, n, m, x.device)
         jobs[j] = nat.LutJob(out.data_ptr(), q.data_ptr(), xh.data_ptr(), cb.data_ptr(), m, k,
-                             1 if (outs is not None and outs_zeroed) else 0)
+                             1 if (outs is not None and outs_zeroed) else 0, _wscale_arg(wscales, j, m), float(oscale),
+                             _ldo(out, n, m))
         results.append(out)
         keep += [q, cb]
     zp, zb = _prezero_args(prezero)

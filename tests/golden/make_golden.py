@@ -15,6 +15,10 @@ Reference entry points used (paths relative to /root/reference):
   lib/algo/ldlq.py              _INV_PERMUTE
   lib/quantizer/quant_op.py     pack_qweight, dequantize_mat_sq_inds(_vec2), pack_qweight_vq_simt,
                                 pack_qweight_sq_simt, convert_tensor_core_to_simt
+  lib/utils/matmul_had.py       get_hadK, matmul_hadU, matmul_hadUt (the pure-torch transform; the *_cuda variants
+                                need the absent third-party fast_hadamard_transform)
+
+    python tests/golden/make_golden.py hadamard      # only (re)generate hadamard.npz
 """
 import os
 import sys
@@ -138,7 +142,34 @@ def gen_tc_to_simt(rng, m, k, bits, vec):
                 idx=Q.numpy().astype(np.int32))
 
 
+def gen_hadamard():
+    """get_hadK sign matrices and matmul_hadU / matmul_hadUt outputs (float64) for the block sizes the build
+    constructs itself (K = 1, 12, 20, 28, 36, 60) at small n, plus the two Llama-3.1-8B sizes."""
+    from lib.utils.matmul_had import get_hadK, matmul_hadU, matmul_hadUt
+    rng = np.random.default_rng(20251011)
+    out = {}
+    for K in (12, 20, 28, 36, 60, 108, 140):
+        hadK, kk = get_hadK(K * 16)
+        assert kk == K
+        h = hadK.numpy()
+        assert np.all(np.abs(h) == 1)
+        out[f"hadK_{K}"] = np.packbits(h > 0, axis=1)          # sign bits, row-major
+    sizes = [64, 128, 12 * 16, 20 * 32, 28 * 16, 36 * 16, 60 * 16, 4096, 14336]
+    for n in sizes:
+        x = rng.standard_normal((2, n)).astype(np.float32)
+        xt = torch.from_numpy(x).to(torch.float64)
+        out[f"x_{n}"] = x
+        out[f"hadU_{n}"] = matmul_hadU(xt).numpy()
+        out[f"hadUt_{n}"] = matmul_hadUt(xt).numpy()
+        print(f"hadamard n={n} K={get_hadK(n)[1]} ok", flush=True)
+    np.savez_compressed(os.path.join(OUT, "hadamard.npz"), sizes=np.array(sizes), **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "hadamard":
+        gen_hadamard()
+        return
+    gen_hadamard()
     rng = np.random.default_rng(20251010)
     out = {}
     m, k = 64, 160
