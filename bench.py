@@ -62,6 +62,12 @@ def parse_args():
                          "Q-Palette checkpoints where every layer stores a copy of the same k-means codebook)")
     ap.add_argument("--no-prezero", action="store_true",
                     help="A/B switch: let down_proj's split-K zero its output with its own memset node")
+    ap.add_argument("--incoherent", action="store_true",
+                    help="run every projection group inside the reference's incoherence wrapper: sign flip + Hadamard + "
+                         "1/scale before (one qpal_hadamard launch, SwiGLU fused for down_proj), Wscale*scale fused into "
+                         "the GEMV epilogue (SURVEY §8 f-1)")
+    ap.add_argument("--no-fuse-rotation", action="store_true",
+                    help="--incoherent: always rotate in a launch of its own (default: inside the GEMV where k allows)")
     ap.add_argument("--layers", type=int, default=0, help="override the number of layers (0 = model's)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo to rehearse ranks on one GPU")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: put every rank on this GPU")
@@ -221,7 +227,69 @@ def main():
     main_stream = torch.cuda.Stream(device)
     side = [torch.cuda.Stream(device) for _ in range(2)] if args.streams >= 3 else []
 
+    inc = None
+    if args.incoherent:
+        assert args.launch == "multi" and gather is None, "--incoherent runs on the multi-job launch path"
+        had = qp.hadamard
+        gen = torch.Generator(device=device).manual_seed(4321)
+        inc = []
+        for groups in layers:
+            per = []
+            for grp in groups:
+                k = grp[0][1]
+                hadK, K = had.get_hadK(k)
+                per.append({
+                    "su": (torch.randint(0, 2, (k,), device=device, generator=gen) * 2 - 1).half(),
+                    "hadK": None if hadK is None else hadK.T.contiguous().half().to(device), "K": K,
+                    "wscale": [(0.01 + 0.02 * torch.rand(m.out_features, device=device, generator=gen)).half()
+                               for m, _, _ in grp]})
+            inc.append(per)
+
+    nrot = [0]  # rotation launches of one token (beyond the SwiGLU one of every layer)
+
+    def token_incoherent():
+        """[rotate -> one multi-job GEMV with fused Wscale*scale] x 4 per layer; down_proj's rotation also applies
+        SwiGLU to the up|gate buffer the previous launch wrote."""
+        outs = []
+        scale = 64.0
+        nrot[0] = 0
+        for groups, per in zip(layers, inc):
+            pre, ug = {}, None
+            for gi, (grp, pi) in enumerate(zip(groups, per)):
+                mods = [m for m, _, _ in grp]
+                wsc = pi["wscale"]
+                if gi == 2 and len(mods) == 2:  # the group is (gate, up); the SwiGLU rotation reads up | gate
+                    mods, wsc = mods[::-1], wsc[::-1]
+                kw = dict(wscales=wsc, oscale=scale)
+                if gi == 3:
+                    xr = had.rotate(ug, hadK=pi["hadK"], K=pi["K"], su=pi["su"], post_scale=1 / scale,
+                                    in_mode=had.IN_SWIGLU_F32)
+                elif pi["K"] == 1 and not args.no_fuse_rotation and qp.linear.rotation_fusable(mods, n):
+                    xr = xs[grp[0][1]]
+                    kw["x_rot"] = (pi["su"], 1 / scale)
+                else:
+                    xr = had.rotate(xs[grp[0][1]], hadK=pi["hadK"], K=pi["K"], su=pi["su"], post_scale=1 / scale)
+                    nrot[0] += 1
+                widths = [m.out_features for m in mods]
+                if gi in (0, 2):
+                    buf = torch.empty((n, sum(widths)), dtype=torch.float32, device=device)
+                    nxt = groups[gi + 1][0][0].out_features
+                    if not args.no_prezero:
+                        pre[gi + 1] = torch.empty((n, nxt), dtype=torch.float32, device=device)
+                        kw["prezero"] = pre[gi + 1]
+                    qp.multi_gemv(mods, xr, outs=list(buf.split(widths, dim=1)), **kw)
+                    if gi == 2:
+                        ug = buf
+                    outs.append(buf)
+                elif gi in pre:
+                    outs += qp.multi_gemv(mods, xr, outs=[pre[gi]], outs_zeroed=True, **kw)
+                else:
+                    outs += qp.multi_gemv(mods, xr, **kw)
+        return outs
+
     def token():
+        if inc is not None:
+            return token_incoherent()
         outs = []
         for groups in layers:
             pre = {}  # group index -> output buffer zeroed by an earlier launch of this block
@@ -320,7 +388,9 @@ def main():
         "config": {"workload": f"{args.workload}: {nlayers} layers, {nlinear} quantized linears ({qstr}), batch {n}, "
                                f"{'HIP-graph replay' if graph is not None else 'eager'}, {args.streams} stream(s)",
                    "parallelism": (f"tp{world} row-sharded + all-gather" if tp else f"dp{world} replicas"),
-                   "linears_per_token": nlinear, "launches_per_token": nlaunch, "launch_mode": args.launch},
+                   "linears_per_token": nlinear, "launches_per_token": nlaunch, "launch_mode": args.launch,
+                   "incoherent": bool(args.incoherent),
+                   "rotation_launches_per_token": (nlayers + nrot[0]) if args.incoherent else 0},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
                      "kernel": "qpal::tc_gemv_kernel (every GEMV launch of a token)",

@@ -64,6 +64,12 @@ typedef struct qpal_tcq_job {
     float oscale;      /* 0 is read as 1 */
     long ldo;          /* row stride of out in floats, >= m; 0 is read as m.  Lets q|k|v or up|gate write the
                           column blocks of one [n][sum m] buffer */
+    int x_had;         /* 1: x is the UN-rotated input; the kernel stages fp16(fp16(H_k (x * x_su) / sqrt(k)) * x_post)
+                          instead — the left rotation of the incoherent wrappers (qpal_hadamard with K = 1, hd = k)
+                          without a launch of its own.  Needs qpal_can_fuse_rotation(n, k); all jobs of a launch
+                          that share x must share x_su / x_post */
+    float x_post;      /* e.g. 1 / scale */
+    const void *x_su;  /* fp16 [k] or NULL */
 } qpal_tcq_job;
 /* prezero/prezero_bytes (may be NULL/0): a buffer this launch also fills with zeros, for a LATER launch on the
  * same stream that accumulates into it with atomics (split-K of a few-rows x long-K layer such as down_proj).
@@ -92,6 +98,9 @@ typedef struct qpal_lut_job {
     const void *wscale;   /* as in qpal_tcq_job */
     float oscale;
     long ldo;
+    int x_had;            /* as in qpal_tcq_job */
+    float x_post;
+    const void *x_su;
 } qpal_lut_job;
 int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits, int vec, void *prezero,
                            long prezero_bytes, void *stream);
@@ -126,12 +135,17 @@ int qpal_tc_to_simt(void *dst_simt, const void *src_tc, int m, int k, int bits, 
  *   hadk      fp16 [K][K] row-major, entries +-1, applied as given (pass the transpose for had_left_T); NULL if K == 1
  *   round_mid 1: fp16 between the butterflies and the hadK product (matmul_hadU_cuda's fp16 pipeline);
  *             0: fp32-grade throughout (matmul_hadU_head_cuda's float path)
- * hd * 4 bytes must fit the 160 KiB LDS (hd <= 40960); K > 1 needs hd / K >= 16.                          */
+ * hd * 4 bytes (+ 1/32 padding) must fit the 160 KiB LDS (hd <= 39 k); K > 1 needs hd / K >= 16; `in` and `su`
+ * 16-byte aligned.                          */
 #define QPAL_IN_F16 0
 #define QPAL_IN_F32 1
 #define QPAL_IN_SWIGLU_F32 2
 int qpal_hadamard(void *out_f16, const void *in, const void *su, const void *sv, const void *hadk,
                   int rows, int n, int hd, int K, int in_mode, int round_mid, float post_scale, void *stream);
+
+/* 1 if the GEMV entry points can apply the rotation themselves (x_had): k in {2048, 4096} and the batch small
+ * enough for x to be staged in LDS; 0 otherwise (then call qpal_hadamard first). */
+int qpal_can_fuse_rotation(int n, int k);
 
 const char *qpal_error_string(int code);
 int qpal_version(void);

@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libqpal_hip.so")
+SO_PATH = os.environ.get("QPAL_LIB") or os.path.join(_HERE, "libqpal_hip.so")  # QPAL_LIB: perf experiments only
 _lib = None
 
 QPAL_SPLIT_NONE, QPAL_SPLIT_ROWS, QPAL_SPLIT_COLS = 0, 1, 2
@@ -18,13 +18,14 @@ _P, _I, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 class TcqJob(ctypes.Structure):
     """qpal_tcq_job (include/qpal.h)"""
     _fields_ = [("out", _P), ("c1", _P), ("c2", _P), ("x", _P), ("tlut", _P), ("m", _I), ("k", _I),
-                ("out_zeroed", _I), ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long)]
+                ("out_zeroed", _I), ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long),
+                ("x_had", _I), ("x_post", _F), ("x_su", _P)]
 
 
 class LutJob(ctypes.Structure):
     """qpal_lut_job (include/qpal.h)"""
     _fields_ = [("out", _P), ("qweight", _P), ("x", _P), ("lut", _P), ("m", _I), ("k", _I), ("out_zeroed", _I),
-                ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long)]
+                ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long), ("x_had", _I), ("x_post", _F), ("x_su", _P)]
 
 
 _SIGNATURES = {
@@ -37,6 +38,7 @@ _SIGNATURES = {
     "qpal_lut_simt_gemv": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "qpal_lut_simt_dequant": [_P, _P, _P, _I, _I, _I, _I, _P],
     "qpal_tc_to_simt": [_P, _P, _I, _I, _I, _I, _P],
+    "qpal_can_fuse_rotation": [_I, _I],
     "qpal_hadamard": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
 }
 

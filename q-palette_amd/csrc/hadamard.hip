@@ -13,6 +13,7 @@
 //      matmul_hadU_head_cuda's float path.
 //   3. out = fp16( fp16(u) * post_scale [* sv] ).
 #include "qpal_common.h"
+#include "wht64.h"
 
 namespace qpal {
 
@@ -28,128 +29,335 @@ struct HadParams {
     int rows, n, hd, K, logP;
     int in_mode, round_mid;
     float pre_scale, post_scale;
+    int npass;             // butterfly passes; pass i handles r[i] index bits in registers (sum r = logP)
+    int r[4];
+    unsigned long long *dbg;  // HAD_STAMPS diagnostic builds: per-wave s_memtime stamps
 };
+
+#ifdef HAD_STAMPS
+#define HAD_STAMP(k)                                                                       \
+    do {                                                                                   \
+        if (p.dbg && (threadIdx.x & 63) == 0) p.dbg[(threadIdx.x >> 6) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define HAD_STAMP(k) do {} while (0)
+#endif
 
 __device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 __device__ __forceinline__ float round_f16(float v) { return (float)(_Float16)v; }
 __device__ __forceinline__ uint16_t f2h(float v) { return __builtin_bit_cast(uint16_t, (_Float16)v); }
 
+// LDS index of element i: one pad word per 32, so that the first pass (every thread writes ITS OWN run of 2^r
+// consecutive elements: lane stride 32 words) spreads over the banks instead of hitting one
+__device__ __forceinline__ int pad(int i) { return i + (i >> 5); }
+
+// 2^R-point Walsh-Hadamard butterflies in registers (Sylvester order: bit s of j <-> index bit b0 + s)
+template <int R>
+__device__ __forceinline__ void butterfly(float (&v)[1 << R]) {
+    static_for<0, R>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+#pragma unroll
+        for (int j = 0; j < (1 << R); j++) {
+            if (!(j & (1 << s))) {
+                const float a = v[j], b = v[j | (1 << s)];
+                v[j] = a + b;
+                v[j | (1 << s)] = a - b;
+            }
+        }
+    });
+}
+
+// 2^R consecutive inputs of row `row` starting at column `col` (+ SwiGLU, + sign flip), with the reference's
+// fp16 rounding points.  16-byte vector loads where the run is long enough (alignment checked by the C-ABI).
+template <int R>
+__device__ __forceinline__ void load_input(const HadParams &p, int row, int col, float (&v)[1 << R]) {
+    constexpr int E = 1 << R;
+    auto load_f32 = [&](const float *src, float (&dst)[E]) {
+        if constexpr (E >= 4) {
+#pragma unroll
+            for (int j = 0; j < E; j += 4) {
+                const float4_t t = *reinterpret_cast<const float4_t *>(src + j);
+                dst[j] = t[0], dst[j + 1] = t[1], dst[j + 2] = t[2], dst[j + 3] = t[3];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; j++) dst[j] = src[j];
+        }
+    };
+    auto load_f16 = [&](const uint16_t *src, float (&dst)[E]) {
+        if constexpr (E >= 8) {
+#pragma unroll
+            for (int j = 0; j < E; j += 8) {
+                const half8_t t = *reinterpret_cast<const half8_t *>(src + j);
+#pragma unroll
+                for (int e = 0; e < 8; e++) dst[j + e] = (float)t[e];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; j++) dst[j] = h2f(src[j]);
+        }
+    };
+    if (p.in_mode == QPAL_IN_F16) {
+        load_f16(static_cast<const uint16_t *>(p.in) + (long)row * p.n + col, v);
+    } else if (p.in_mode == QPAL_IN_F32) {
+        load_f32(static_cast<const float *>(p.in) + (long)row * p.n + col, v);
+#pragma unroll
+        for (int j = 0; j < E; j++) v[j] = round_f16(v[j]);
+    } else {
+        const float *src = static_cast<const float *>(p.in) + (long)row * 2 * p.n + col;
+        constexpr int CH = E < 4 ? E : 4;
+#pragma unroll
+        for (int j = 0; j < E; j += CH) {
+            float up[CH], gate[CH];
+            if constexpr (CH == 4) {
+                const float4_t tu = *reinterpret_cast<const float4_t *>(src + j);
+                const float4_t tg = *reinterpret_cast<const float4_t *>(src + p.n + j);
+#pragma unroll
+                for (int e = 0; e < 4; e++) up[e] = tu[e], gate[e] = tg[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < CH; e++) up[e] = src[j + e], gate[e] = src[p.n + j + e];
+            }
+#pragma unroll
+            for (int e = 0; e < CH; e++) {
+                const float u = round_f16(up[e]), gt = round_f16(gate[e]);
+                v[j + e] = round_f16(round_f16(gt / (1.0f + __expf(-gt))) * u);
+            }
+        }
+    }
+    if (p.su) {
+        if constexpr (E >= 8) {
+#pragma unroll
+            for (int j = 0; j < E; j += 8) {
+                const half8_t t = *reinterpret_cast<const half8_t *>(p.su + col + j);
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[j + e] = round_f16(v[j + e] * (float)t[e]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; j++) v[j] = round_f16(v[j] * h2f(p.su[col + j]));
+        }
+    }
+}
+
+// One butterfly pass over index bits [b0, b0 + R): every thread owns whole 2^R-element groups in registers.
+// FROM_GLOBAL: the first pass (b0 = 0) reads its contiguous run straight from the input; TO_OUT: the last pass of
+// a K = 1 transform scales, rounds and stores fp16 without going back through LDS.
+template <int R, bool FROM_GLOBAL, bool TO_OUT, int NT>
+__device__ __forceinline__ void had_pass(const HadParams &p, float *buf, int b0, int row, int col0, int tid) {
+    constexpr int E = 1 << R;
+    const int ngroups = p.hd >> R;
+    for (int g = tid; g < ngroups; g += NT) {
+        const int i0 = ((g >> b0) << (b0 + R)) | (g & ((1 << b0) - 1));
+        float v[E];
+        if constexpr (FROM_GLOBAL) {
+            load_input<R>(p, row, col0 + i0, v);
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; j++) v[j] = buf[pad(i0 + (j << b0))];
+        }
+        butterfly<R>(v);
+        if constexpr (TO_OUT) {
+            uint16_t *orow = p.out + (long)row * p.n + col0;
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const int i = i0 + (j << b0);
+                float u = round_f16(v[j] * p.pre_scale) * p.post_scale;
+                if (p.sv) u = round_f16(u) * h2f(p.sv[col0 + i]);
+                orow[i] = f2h(u);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; j++) buf[pad(i0 + (j << b0))] = v[j];
+        }
+    }
+}
+
+template <bool FROM_GLOBAL, bool TO_OUT, int NT>
+__device__ __forceinline__ void had_pass_r(int r, const HadParams &p, float *buf, int b0, int row, int col0, int tid) {
+    switch (r) {
+        case 1: had_pass<1, FROM_GLOBAL, TO_OUT, NT>(p, buf, b0, row, col0, tid); break;
+        case 2: had_pass<2, FROM_GLOBAL, TO_OUT, NT>(p, buf, b0, row, col0, tid); break;
+        case 3: had_pass<3, FROM_GLOBAL, TO_OUT, NT>(p, buf, b0, row, col0, tid); break;
+        case 4: had_pass<4, FROM_GLOBAL, TO_OUT, NT>(p, buf, b0, row, col0, tid); break;
+        default: had_pass<5, FROM_GLOBAL, TO_OUT, NT>(p, buf, b0, row, col0, tid); break;
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void had_kernel(HadParams p) {
-    extern __shared__ float buf[];  // hd floats
+    extern __shared__ float buf[];  // hd floats, padded (pad())
     const int tid = threadIdx.x;
     const int bpr = p.n / p.hd;
     const int row = blockIdx.x / bpr, blk = blockIdx.x - row * bpr;
     const int col0 = blk * p.hd;
-    const int hd = p.hd;
-
-    // ---- load (+ SwiGLU, + sign flip); the reference's fp16 rounding points are kept
-    for (int i = tid; i < hd; i += NT) {
-        const int col = col0 + i;
-        float v;
-        if (p.in_mode == QPAL_IN_F16) {
-            v = h2f(static_cast<const uint16_t *>(p.in)[(long)row * p.n + col]);
-        } else if (p.in_mode == QPAL_IN_F32) {
-            v = round_f16(static_cast<const float *>(p.in)[(long)row * p.n + col]);
-        } else {
-            const float *src = static_cast<const float *>(p.in) + (long)row * 2 * p.n;
-            const float up = round_f16(src[col]), gate = round_f16(src[p.n + col]);
-            const float act = round_f16(gate / (1.0f + __expf(-gate)));
-            v = round_f16(act * up);
-        }
-        if (p.su) v = round_f16(v * h2f(p.su[col]));
-        buf[i] = v;
-    }
-    __syncthreads();
-
-    // ---- WHT over the low logP index bits: radix-4 passes, then one radix-2 pass if logP is odd
-    int b = 0;
-    for (; b + 2 <= p.logP; b += 2) {
-        const int lowmask = (1 << b) - 1;
-        for (int g = tid; g < (hd >> 2); g += NT) {
-            const int base = ((g >> b) << (b + 2)) | (g & lowmask);
-            const float a0 = buf[base], a1 = buf[base + (1 << b)], a2 = buf[base + (2 << b)], a3 = buf[base + (3 << b)];
-            const float s0 = a0 + a1, d0 = a0 - a1, s1 = a2 + a3, d1 = a2 - a3;
-            buf[base] = s0 + s1;
-            buf[base + (1 << b)] = d0 + d1;
-            buf[base + (2 << b)] = s0 - s1;
-            buf[base + (3 << b)] = d0 - d1;
-        }
-        __syncthreads();
-    }
-    if (b < p.logP) {
-        const int lowmask = (1 << b) - 1;
-        for (int g = tid; g < (hd >> 1); g += NT) {
-            const int base = ((g >> b) << (b + 1)) | (g & lowmask);
-            const float a0 = buf[base], a1 = buf[base + (1 << b)];
-            buf[base] = a0 + a1;
-            buf[base + (1 << b)] = a0 - a1;
-        }
-        __syncthreads();
-    }
-
-    uint16_t *orow = p.out + (long)row * p.n + col0;
-    if (p.K == 1) {
-        for (int i = tid; i < hd; i += NT) {
-            float u = round_f16(buf[i] * p.pre_scale) * p.post_scale;
-            if (p.sv) u = round_f16(u) * h2f(p.sv[col0 + i]);
-            orow[i] = f2h(u);
-        }
-        return;
-    }
-
-    // ---- hadK over the K axis: D[j][c] = sum_i hadK[j][i] * t[i][c], 16 columns per MFMA tile
-    const int P = 1 << p.logP;
     const int lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, c16 = lane & 15;
+
+    HAD_STAMP(0);
+    // hadK A fragments of the common K <= 32 case go out first: their latency hides behind the input's
+    const bool hoist = p.K > 1 && p.K <= 32;
+    uint16_t araw[2][8];  // raw loads only: converting here would wait for them before the input is even requested
+    if (hoist) {
+#pragma unroll
+        for (int jt = 0; jt < 2; jt++) {
+            const int ja = (jt << 4) + c16;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int i = (q << 3) + e;
+                araw[jt][e] = p.hadk[(ja < p.K ? ja : p.K - 1) * p.K + (i < p.K ? i : p.K - 1)];
+            }
+        }
+    }
+
+    // ---- WHT over the low logP index bits
+    const bool direct = p.K == 1;  // the last pass writes the output itself
+    int b0 = 0;
+    for (int ps = 0; ps < p.npass; ps++) {
+        const int r = p.r[ps];
+        const bool last = ps == p.npass - 1;
+        if (ps == 0) {
+            if (last && direct) had_pass_r<true, true, NT>(r, p, buf, 0, row, col0, tid);
+            else had_pass_r<true, false, NT>(r, p, buf, 0, row, col0, tid);
+        } else {
+            if (last && direct) had_pass_r<false, true, NT>(r, p, buf, b0, row, col0, tid);
+            else had_pass_r<false, false, NT>(r, p, buf, b0, row, col0, tid);
+        }
+        b0 += r;
+        HAD_STAMP(1 + 2 * ps);
+        if (!(last && direct)) __syncthreads();
+        HAD_STAMP(2 + 2 * ps);
+    }
+    if (direct) return;
+
+    // ---- hadK over the K axis: D[j][c] = sum_i hadK[j][i] * t[i][c], 16 columns per MFMA tile.
+    // All loads are unconditional (clamped index, masked value) so that they issue back to back.
+    uint16_t *orow = p.out + (long)row * p.n + col0;
+    const int P = 1 << p.logP;
     const int njt = (p.K + 15) >> 4, nkc = (p.K + 31) >> 5;
+    half8_t afr[2];
+    if (hoist) {
+#pragma unroll
+        for (int jt = 0; jt < 2; jt++) {
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                afr[jt][e] = ((q << 3) + e < p.K && (jt << 4) + c16 < p.K) ? __builtin_bit_cast(_Float16, araw[jt][e])
+                                                                           : (_Float16)0.f;
+        }
+    }
+    auto b_fragment = [&](int kc, int c, half8_t &bh, half8_t &bl) {
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int i = (kc << 5) + (q << 3) + e;
+            t[e] = buf[pad((i < p.K ? i : p.K - 1) * P + c)];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int i = (kc << 5) + (q << 3) + e;
+            const float v = i < p.K ? t[e] * p.pre_scale : 0.f;
+            const _Float16 hi = (_Float16)v;
+            bh[e] = hi;
+            bl[e] = p.round_mid ? (_Float16)0.f : (_Float16)(v - (float)hi);
+        }
+    };
+    auto store_tile = [&](int jt, int c, const float4_t &acc) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int j = (jt << 4) + (q << 2) + r;
+            if (j < p.K) {
+                float u = round_f16(acc[r]) * p.post_scale;
+                if (p.sv) u = round_f16(u) * h2f(p.sv[col0 + j * P + c]);
+                orow[j * P + c] = f2h(u);
+            }
+        }
+    };
     for (int ct = wave; ct < (P >> 4); ct += NT / 64) {
         const int c = (ct << 4) + c16;
+        if (hoist) {  // K <= 32: one B fragment serves both row tiles
+            half8_t bh, bl;
+            b_fragment(0, c, bh, bl);
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++) {
+                if (jt < njt) {
+                    float4_t acc{0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[jt], bh, acc, 0, 0, 0);
+                    if (!p.round_mid) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[jt], bl, acc, 0, 0, 0);
+                    store_tile(jt, c, acc);
+                }
+            }
+            continue;
+        }
         for (int jt = 0; jt < njt; jt++) {
             float4_t acc{0.f, 0.f, 0.f, 0.f};
             const int ja = (jt << 4) + c16;  // A operand: row of hadK
             for (int kc = 0; kc < nkc; kc++) {
                 half8_t a, bh, bl;
+                uint16_t ah[8];
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     const int i = (kc << 5) + (q << 3) + e;
-                    const bool in_k = i < p.K;
-                    a[e] = (in_k && ja < p.K) ? __builtin_bit_cast(_Float16, p.hadk[ja * p.K + i]) : (_Float16)0.f;
-                    const float t = in_k ? buf[i * P + c] * p.pre_scale : 0.f;
-                    const _Float16 hi = (_Float16)t;
-                    bh[e] = hi;
-                    bl[e] = (_Float16)(t - (float)hi);
+                    ah[e] = p.hadk[(ja < p.K ? ja : p.K - 1) * p.K + (i < p.K ? i : p.K - 1)];
                 }
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int i = (kc << 5) + (q << 3) + e;
+                    a[e] = (i < p.K && ja < p.K) ? __builtin_bit_cast(_Float16, ah[e]) : (_Float16)0.f;
+                }
+                b_fragment(kc, c, bh, bl);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh, acc, 0, 0, 0);
                 if (!p.round_mid) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl, acc, 0, 0, 0);
             }
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int j = (jt << 4) + (q << 2) + r;
-                if (j < p.K) {
-                    float u = round_f16(acc[r]) * p.post_scale;
-                    if (p.sv) u = round_f16(u) * h2f(p.sv[col0 + j * P + c]);
-                    orow[j * P + c] = f2h(u);
-                }
-            }
+            store_tile(jt, c, acc);
         }
     }
+    HAD_STAMP(7);
+}
+
+// K = 1, hd = 1024 .. 8192: the whole transform on the matrix pipe (wht64.h), one wave quad per block of hd
+template <int RT>
+__global__ __launch_bounds__(256) void had_mfma_kernel(HadParams p) {
+    const int bpr = p.n / p.hd;
+    const int row = blockIdx.x / bpr, blk = blockIdx.x - row * bpr;
+    const int col0 = blk * p.hd;
+    const int lane = threadIdx.x & 63, ct = threadIdx.x >> 6;
+    uint16_t *orow = p.out + (long)row * p.n + col0;
+    wht64_quad<RT>(
+        ct, lane, p.pre_scale,
+        [&](int t, int kc) {  // fp16 input only: x * su is one packed multiply per dword (rounds like the reference)
+            const long off = (long)row * p.n + col0 + (16 * t + (lane & 15)) * 64 + 32 * kc + 8 * (lane >> 4);
+            wht_half8 h = *reinterpret_cast<const wht_half8 *>(static_cast<const uint16_t *>(p.in) + off);
+            if (p.su) h = h * *reinterpret_cast<const wht_half8 *>(p.su + (off - (long)row * p.n));
+            return h;
+        },
+        [&](int, int, int i, float v) {
+            float u = round_f16(v) * p.post_scale;
+            if (p.sv) u = round_f16(u) * h2f(p.sv[col0 + i]);
+            orow[i] = f2h(u);
+        });
 }
 
 int launch_hadamard(const HadParams &p, hipStream_t stream) {
+    if (p.K == 1 && p.in_mode == QPAL_IN_F16 && (p.hd == 1024 || p.hd == 2048 || p.hd == 4096)) {  // 8192: the butterflies win (measured)
+        const int g = p.rows * (p.n / p.hd);
+        if (p.hd == 1024) hipLaunchKernelGGL((had_mfma_kernel<1>), dim3(g), dim3(256), 0, stream, p);
+        else if (p.hd == 2048) hipLaunchKernelGGL((had_mfma_kernel<2>), dim3(g), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((had_mfma_kernel<4>), dim3(g), dim3(256), 0, stream, p);
+        return (int)hipGetLastError();
+    }
     const int grid = p.rows * (p.n / p.hd);
-    const size_t lds = sizeof(float) * (size_t)p.hd;
-    if (p.hd <= 1024) {
+    const size_t lds = sizeof(float) * (size_t)(p.hd + (p.hd >> 5) + 1);
+    if (p.hd <= 4096) {  // <= 256 groups of 16: four waves do it
         hipLaunchKernelGGL((had_kernel<256>), dim3(grid), dim3(256), lds, stream, p);
     } else {
         static bool attr_set = false;
         if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in (idempotent; races are harmless)
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&had_kernel<1024>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&had_kernel<768>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
-        hipLaunchKernelGGL((had_kernel<1024>), dim3(grid), dim3(1024), lds, stream, p);
+        hipLaunchKernelGGL((had_kernel<768>), dim3(grid), dim3(768), lds, stream, p);
     }
     return (int)hipGetLastError();
 }
@@ -157,6 +365,11 @@ int launch_hadamard(const HadParams &p, hipStream_t stream) {
 }  // namespace qpal
 
 using namespace qpal;
+
+#ifdef HAD_STAMPS
+static unsigned long long *g_had_dbg = nullptr;
+extern "C" void qpal_debug_had_stamps(void *buf) { g_had_dbg = static_cast<unsigned long long *>(buf); }
+#endif
 
 extern "C" int qpal_hadamard(void *out_f16, const void *in, const void *su, const void *sv, const void *hadk, int rows,
                              int n, int hd, int K, int in_mode, int round_mid, float post_scale, void *stream) {
@@ -167,14 +380,33 @@ extern "C" int qpal_hadamard(void *out_f16, const void *in, const void *su, cons
     const int P = hd / K;
     if (P & (P - 1)) return QPAL_E_SHAPE;
     if (K > 1 && P < 16) return QPAL_E_SHAPE;
-    if (hd < 4 || hd * sizeof(float) > 160 * 1024) return QPAL_E_SHAPE;
+    if (hd < 2 || (hd + (hd >> 5) + 1) * sizeof(float) > 160 * 1024) return QPAL_E_SHAPE;
     int logP = 0;
     while ((1 << logP) < P) logP++;
     const uintptr_t al = reinterpret_cast<uintptr_t>(out_f16) | reinterpret_cast<uintptr_t>(su) |
                          reinterpret_cast<uintptr_t>(sv) | reinterpret_cast<uintptr_t>(hadk);
-    if ((al & 1) || (reinterpret_cast<uintptr_t>(in) & (in_mode == QPAL_IN_F16 ? 1 : 3))) return QPAL_E_ALIGN;
+    if (al & 1) return QPAL_E_ALIGN;
+    // the first pass reads runs of 2^r elements with 16-byte vector loads
+    if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(su)) & 15) return QPAL_E_ALIGN;
+    if (((size_t)n * (in_mode == QPAL_IN_F16 ? 2 : 4)) % 16 && rows > 1) return QPAL_E_ALIGN;
     HadParams p{static_cast<uint16_t *>(out_f16), in, static_cast<const uint16_t *>(su), static_cast<const uint16_t *>(sv),
                 static_cast<const uint16_t *>(hadk), rows, n, hd, K, logP, in_mode, round_mid ? 1 : 0,
-                (float)(1.0 / sqrt((double)hd)), post_scale};
+                (float)(1.0 / sqrt((double)hd)), post_scale, 0, {0, 0, 0, 0}, nullptr};
+#ifdef HAD_STAMPS
+    p.dbg = g_had_dbg;
+#endif
+    // pass plan: 5 bits first (the next pass then strides by >= 32 floats: conflict-free LDS columns), the rest even
+    const int first = 5;
+    int left = logP;
+    if (left > 0) {
+        p.r[p.npass++] = left < first ? left : first;
+        left -= p.r[0];
+        const int more = (left + 4) / 5;
+        for (int i = 0; i < more; i++) {
+            const int take = (left + (more - i) - 1) / (more - i);
+            p.r[p.npass++] = take;
+            left -= take;
+        }
+    }
     return launch_hadamard(p, static_cast<hipStream_t>(stream));
 }

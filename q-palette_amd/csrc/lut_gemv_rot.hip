@@ -1,0 +1,17 @@
+// VQ/SQ tensor-core-format GEMV kernels that also apply the incoherence rotation to x while staging it.
+#include "lut_kernels_api.h"
+
+namespace qpal {
+
+int launch_lut_tc_gemv_rot(const TcMultiParams &p, int bits, int vec, int grid, hipStream_t stream) {
+#define QPAL_LUT(B_, V_)                                                                                           \
+    if (bits == B_ && vec == V_) {                                                                                 \
+        hipLaunchKernelGGL((tc_gemv_kernel<LutCodec<B_, V_>, void, 1, true>), dim3(grid), dim3(1024), 0, stream, p); \
+        return (int)hipGetLastError();                                                                             \
+    }
+#include "lut_table.inc"
+#undef QPAL_LUT
+    return QPAL_E_PARAM;
+}
+
+}  // namespace qpal

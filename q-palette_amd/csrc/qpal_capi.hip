@@ -1,6 +1,7 @@
 // C-ABI entry points (include/qpal.h): argument checks, launch geometry, dispatch.  No allocation, no
 // synchronisation, everything on the caller's stream (graph-capturable).
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdlib.h>
 
 #include "lut_kernels_api.h"
@@ -39,6 +40,22 @@ bool simt_ok(int bits, int vec) {
 int x_fits_lds(int n, int k) {
     static const int no_xlds = getenv("QPAL_NO_XLDS") != nullptr;
     return !no_xlds && n <= 8 && 16 * 32 * 4 * n + 2 * n * k + 64 <= kScratchBytes && (n * k) % 8 == 0;
+}
+
+// (k = 8192 would need the 8-row-tile transform: its registers do not fit the GEMV kernel's 128-VGPR budget)
+bool rot_ok(int n, int k) { return (k == 2048 || k == 4096) && x_fits_lds(n, k); }
+
+// x_had of a job -> kernel parameters; QPAL_E_SHAPE where the fused rotation is not available
+int set_rotation(TcParams &p, int x_had, const void *x_su, float x_post, int n, int k) {
+    if (!x_had) return QPAL_OK;
+    if (!rot_ok(n, k)) return QPAL_E_SHAPE;
+    if (x_su && !aligned(x_su, 16)) return QPAL_E_ALIGN;
+    if (!aligned(p.x, 16)) return QPAL_E_ALIGN;
+    p.x_rot = k / 1024;
+    p.x_su = static_cast<const uint16_t *>(x_su);
+    p.x_pre = (float)(1.0 / sqrt((double)k));
+    p.x_post = x_post;
+    return QPAL_OK;
 }
 
 int nb_of(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : 8; }
@@ -228,6 +245,8 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         else
             tcq_fill(mp.job[j], jb.out, ldo, jb.c1, jb.c2, jb.x, jb.tlut, jb.m, n, jb.k, jb.k / 2, jb.k / 2, jb.wscale,
                      jb.oscale);
+        rc = set_rotation(mp.job[j], jb.x_had, jb.x_su, jb.x_post, n, jb.k);
+        if (rc) return rc;
         zeroed[j] = jb.out_zeroed;
     }
     mp.zero = static_cast<u32x4 *>(prezero);
@@ -301,7 +320,7 @@ static int lut_args_ok(const void *out, const void *qweight, const void *x, cons
 
 int qpal_lut_tc_gemv(float *out, const void *qweight, const void *x, const void *lut, int m, int n, int k, int bits,
                      int vec, void *stream) {
-    qpal_lut_job job{out, qweight, x, lut, m, k, 0, nullptr, 1.0f, 0};
+    qpal_lut_job job{out, qweight, x, lut, m, k, 0, nullptr, 1.0f, 0, 0, 1.0f, nullptr};
     return qpal_lut_tc_gemv_multi(&job, 1, n, bits, vec, nullptr, 0, stream);
 }
 
@@ -321,6 +340,8 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
         if (jb.wscale && !aligned(jb.wscale, 2)) return QPAL_E_ALIGN;
         if (jb.ldo != 0 && jb.ldo < jb.m) return QPAL_E_SHAPE;
         lut_fill(mp.job[j], jb.out, jb.ldo ? jb.ldo : jb.m, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k, jb.wscale, jb.oscale);
+        rc = set_rotation(mp.job[j], jb.x_had, jb.x_su, jb.x_post, n, jb.k);
+        if (rc) return rc;
         zeroed[j] = jb.out_zeroed;
     }
     mp.zero = static_cast<u32x4 *>(prezero);
@@ -390,6 +411,8 @@ int qpal_tc_to_simt(void *dst_simt, const void *src_tc, int m, int k, int bits, 
     if (e != hipSuccess) return (int)e;
     return launch_tc_to_simt(static_cast<uint32_t *>(dst_simt), static_cast<const uint32_t *>(src_tc), m, k, bits, vec, s);
 }
+
+int qpal_can_fuse_rotation(int n, int k) { return n >= 1 && k > 0 && rot_ok(n, k) ? 1 : 0; }
 
 const char *qpal_error_string(int code) {
     switch (code) {

@@ -25,6 +25,7 @@
 //    column half u), so batches 1..8 cost the same VALU work.  fp32 accumulation.
 #pragma once
 #include "qpal_common.h"
+#include "wht64.h"
 
 namespace qpal {
 
@@ -52,6 +53,9 @@ struct TcParams {
     int x_lds;          // 1: stage x[n][k] in LDS (fits beside the codebook image)
     int base1, rem1;    // stream 1: st1 = nc1*base1 + rem1 (first rem1 chunks get one more step)
     int base2, rem2;    // stream 2: st2 = (nchunk-nc1)*base2 + rem2
+    const uint16_t *x_su;    // gemv prologue rotation (x_rot != 0): fp16 [k] sign vector or null
+    float x_pre, x_post;     //   staged x = fp16( fp16( H_k (x * su) * x_pre ) * x_post ), x_pre = k^-1/2
+    int x_rot;               //   0: x is used as given; else k / 1024 (k in {2048, 4096}), needs x_lds
     const uint16_t *wscale;  // gemv epilogue: fp16 [m] per-output-row scale or null
     float oscale;            // gemv epilogue: out = acc * wscale[row] * oscale
     unsigned long long *dbg;  // QPAL_STAMPS diagnostic builds only: per-wave s_memtime stamps
@@ -365,7 +369,9 @@ constexpr int scratch_bytes() { return NBG == 1 ? kScratchBytes : 16 * 32 * 4 * 
 // c2 via C2); both codecs share one codebook image.  A wave's chunk of steps never straddles the two streams.
 // When they fit beside the codebook image (batch <= 8) the activations are staged once per workgroup in LDS.
 // All index arithmetic is shift/compare: the host passes the chunk partition (base/rem) precomputed.
-template <class C1, class C2, int NBG>
+// ROT: instantiation that can rotate x while staging it (x_rot jobs); plain launches run the ROT = false kernels,
+// which do not carry that code (it costs ~3 % of a plain token when merely present: measured)
+template <class C1, class C2, int NBG, bool ROT = false>
 __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
     constexpr bool TWO = !std::is_void_v<C2>;
     using CB = std::conditional_t<TWO, C2, C1>;
@@ -423,6 +429,11 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
         }
         const int sr = (rg << log2_rpw) + rloc;
         const bool live = sr < p.nrows;
+        // per-row output scale of the epilogue: requested now, consumed after the steps (a load issued there
+        // would put a whole memory round trip at the end of the kernel)
+        uint16_t wraw = 0x3C00;  // 1.0
+        if (p.wscale && tid < (32 << log2_rpw) && (rg << log2_rpw) + (tid >> 5) < p.nrows)
+            wraw = p.wscale[((rg << log2_rpw) + (tid >> 5)) * 32 + (tid & 31)];
         const int c = ks * wpr + wr;
         // chunk c -> (stream, [s0, s1)): chunk j of a stream covers base steps, the first rem chunks one more
         const bool on2 = TWO && c >= p.nc1;
@@ -446,17 +457,47 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
         else load_step_w<C1::NW>(sv1, s0, lane, w.a);
         QPAL_STAMP(1);
         if (p.tab != cur_tab || (x_lds && p.x != cur_x)) {  // workgroup-uniform
+            [[maybe_unused]] int build_first = 0;  // ROT: waves below this one rotate x, the others build the image
             if (x_lds && p.x != cur_x) {
                 const int total = p.n * p.k;  // multiple of 8 halves
-                for (int i = tid * 8; i < total + 32; i += 1024 * 8) {
-                    u32x4 v{0u, 0u, 0u, 0u};
-                    if (i < total) v = *reinterpret_cast<const u32x4 *>(p.x + i);
-                    *reinterpret_cast<u32x4 *>(xs + i) = v;
+                if (ROT && p.x_rot) {
+                  if constexpr (ROT) {
+                    // Incoherence rotation fused into the staging: wave quad g transforms batch rows g, g + nq, ...
+                    // straight from global memory into the LDS copy (wht64.h: matrix pipe, no barrier inside) while
+                    // the other waves build the codebook image.  (Staging x * su in LDS first and rotating from
+                    // there — one global read per workgroup instead of four — measured slower: two more barriers.)
+                    const int nq = p.n < 3 ? p.n : 3;  // quads that rotate (at least one quad keeps building)
+                    build_first = 4 * nq;
+                    if (wave < build_first) {
+                        for (int b = wave >> 2; b < p.n; b += nq) {
+                            const uint16_t *xrow = p.x + (long)b * p.k;
+                            uint16_t *dst = xs + b * p.k;
+                            auto load_a = [&](int t, int kc) {
+                                const int off = (16 * t + (lane & 15)) * 64 + 32 * kc + 8 * (lane >> 4);
+                                wht_half8 h = *reinterpret_cast<const wht_half8 *>(xrow + off);
+                                if (p.x_su) h = h * *reinterpret_cast<const wht_half8 *>(p.x_su + off);
+                                return h;
+                            };
+                            auto store = [&](int, int, int i, float v) {
+                                dst[i] = __builtin_bit_cast(uint16_t, (_Float16)((float)(_Float16)v * p.x_post));
+                            };
+                            if (p.x_rot == 4) wht64_quad<4, 4>(wave & 3, lane, p.x_pre, load_a, store);
+                            else wht64_quad<2, 2>(wave & 3, lane, p.x_pre, load_a, store);
+                        }
+                        if (tid < 32) xs[total + tid] = 0;
+                    }
+                  }
+                } else {
+                    for (int i = tid * 8; i < total + 32; i += 1024 * 8) {
+                        u32x4 v{0u, 0u, 0u, 0u};
+                        if (i < total) v = *reinterpret_cast<const u32x4 *>(p.x + i);
+                        *reinterpret_cast<u32x4 *>(xs + i) = v;
+                    }
                 }
                 cur_x = p.x;
             }
             if (p.tab != cur_tab) {
-                C1::build(lut, p.tab, tid, 1024);
+                if (wave >= build_first) C1::build(lut, p.tab, tid - 64 * build_first, 1024 - 64 * build_first);
                 cur_tab = p.tab;
             }
             QPAL_STAMP(2);
@@ -506,8 +547,8 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
             const int r = tid & 31, rl = tid >> 5;
             const int srow = (rg << log2_rpw) + rl;
             if (srow < p.nrows) {
-                float osc = p.oscale;  // the incoherent wrappers' `* Wscale * scale`, fused
-                if (p.wscale) osc *= (float)__builtin_bit_cast(_Float16, p.wscale[srow * 32 + r]);
+                // the incoherent wrappers' `* Wscale * scale`, fused
+                const float osc = p.oscale * (float)__builtin_bit_cast(_Float16, wraw);
                 for (int b = 0; b < p.n; b++) {
                     float v = 0.f;
                     for (int qq = 0; qq < wpr; qq++) v += red[(((rl << p.log2_wpr) + qq) * p.n + b) * 32 + r];

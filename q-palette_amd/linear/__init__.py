@@ -74,7 +74,14 @@ def launch_groups(layers):
     return out
 
 
-def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=None, oscale=1.0):
+def rotation_fusable(layers, n):
+    """True if multi_gemv(..., x_rot=...) can apply the left rotation inside the GEMV launches of `layers`."""
+    from .. import ops
+    return (all(_codec_key(l)[0] != "single" for l in layers)
+            and ops.can_fuse_rotation(n, layers[0].in_features))
+
+
+def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=None, oscale=1.0, x_rot=None):
     """y_i = layers[i](x) for several quantized linears that share the input, batch <= 8.  Layers of one
     kind and codec (e.g. q|k|v or gate|up of one block) go out as ONE kernel launch per codec
     (C-ABI qpal_*_gemv_multi); anything else is one launch per layer.  Returns fp32/fp16 [n, m_i] tensors in
@@ -84,7 +91,9 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
     memset of its own); prezero: a tensor the first multi-job launch also zeroes — the way a decode block
     prepares down_proj's output during the gate|up launch.
     wscales (fp16 [m_i] vectors) / oscale: y_i = layers[i](x) * wscales[i] * oscale, fused into the GEMV epilogue for
-    the tensor-core-order families (the `* Wscale * scale` of the incoherent wrappers)."""
+    the tensor-core-order families (the `* Wscale * scale` of the incoherent wrappers).
+    x_rot = (su, post_scale): x is the UN-rotated input and every launch stages fp16(fp16(H (x*su)/sqrt(k)) * post)
+    itself (only where rotation_fusable(layers, n))."""
     from .. import ops
 
     x2 = x.reshape(-1, layers[0].in_features)
@@ -98,7 +107,7 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
         grp = [layers[i] for i in idxs]
         o = [outs[i] for i in idxs] if outs is not None else None
         ws = [wscales[i] for i in idxs] if wscales is not None else None
-        extra = dict(outs=o, outs_zeroed=outs_zeroed, prezero=prezero, wscales=ws, oscale=oscale)
+        extra = dict(outs=o, outs_zeroed=outs_zeroed, prezero=prezero, wscales=ws, oscale=oscale, x_rot=x_rot)
         if kind == "tcq":
             ys = ops.tcq_gemv_multi([(l.trellis, None, l.tlut, l.out_features) for l in grp], x2, first.tlut_bits,
                                     first.KV, **extra)
@@ -112,6 +121,8 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
                                        first.vec_sz, **extra)
             prezero = None
         else:
+            if x_rot is not None:
+                raise RuntimeError("x_rot needs tensor-core-order packed layers (see rotation_fusable)")
             ys = [first._gemv(x2, n) if n <= first.max_fused_batch else first(x2)]
             if ws is not None and ws[0] is not None:
                 ys = [ys[0].float() * ws[0].float() * oscale]
@@ -129,5 +140,5 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
 
 from .incoherent_linear import IncoherentLinear, IncoherentMLP, IncoherentSdpaAttention, make_linear  # noqa: E402
 
-__all__ = ["IncoherentLinear", "IncoherentMLP", "IncoherentSdpaAttention", "make_linear", "multi_gemv", "launch_groups", "share_codebooks","QTIPLinearTCQ", "CombLinearTCQ", "CombtLinearTCQ", "VQLinearPackTensorCore", "VQLinearPackSIMT",
+__all__ = ["rotation_fusable", "IncoherentLinear", "IncoherentMLP", "IncoherentSdpaAttention", "make_linear", "multi_gemv", "launch_groups", "share_codebooks","QTIPLinearTCQ", "CombLinearTCQ", "CombtLinearTCQ", "VQLinearPackTensorCore", "VQLinearPackSIMT",
            "linear_class_for", "make_linear_from_info"]

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 from .. import hadamard as had
 from .. import mem_op
-from . import linear_class_for, make_linear_from_info, multi_gemv
+from . import linear_class_for, make_linear_from_info, multi_gemv, rotation_fusable
 from ._base import PackedLinearBase
 
 _ACTS = {"silu": F.silu, "swish": F.silu, "gelu": F.gelu, "relu": F.relu}
@@ -58,6 +58,20 @@ def _scaled_linears(layers, x16, wscales, scale, out=None):
     return out
 
 
+def _rotated_linears(layers, x16, su, hadK, K, wscales, scale):
+    """_scaled_linears(layers, rotate(x16 * su) / scale): where the sizes allow (k = 2048 / 4096, small batch,
+    tensor-core-order layers) the rotation runs inside the GEMV launches and costs no launch of its own."""
+    n = x16.shape[0]
+    if K == 1 and n <= 16 and all(isinstance(l, PackedLinearBase) for l in layers) and rotation_fusable(layers, n):
+        widths = [l.out_features for l in layers]
+        out = torch.empty((n, sum(widths)), dtype=torch.float32, device=x16.device)
+        multi_gemv(layers, x16, outs=list(out.split(widths, dim=1)), wscales=wscales, oscale=scale,
+                   x_rot=(su, 1.0 / scale))
+        return out
+    xr = had.rotate(x16, hadK=hadK, K=K, su=su, post_scale=1.0 / scale)
+    return _scaled_linears(layers, xr, wscales, scale)
+
+
 class IncoherentMLP(nn.Module):
     """Left-rotation-only MLP with one SU for up|gate (reference l.275-394)."""
 
@@ -82,12 +96,12 @@ class IncoherentMLP(nn.Module):
     # ---- fused pipeline (what forward runs)
     def _ug_raw(self, x16):
         """fp32 [n, 2I] = up | gate, already `* Wscale_ug * scale`."""
-        xr = had.rotate(x16, hadK=self.had_left_ug_T, K=self.hidden_K, su=self.SU_ug, post_scale=1.0 / self.scale)
         inter = self.intermediate_size
+        rot = (self.SU_ug, self.had_left_ug_T, self.hidden_K)
         if self.merge_ug:
-            return _scaled_linears([self.ug_proj], xr, [self.Wscale_ug], self.scale)
-        return _scaled_linears([self.up_proj, self.gate_proj], xr, [self.Wscale_ug[:inter], self.Wscale_ug[inter:]],
-                               self.scale)
+            return _rotated_linears([self.ug_proj], x16, *rot, [self.Wscale_ug], self.scale)
+        return _rotated_linears([self.up_proj, self.gate_proj], x16, *rot,
+                                [self.Wscale_ug[:inter], self.Wscale_ug[inter:]], self.scale)
 
     def _dp_from_raw(self, ug):
         if self.hidden_act in ("silu", "swish"):
@@ -209,9 +223,8 @@ class IncoherentSdpaAttention(nn.Module):
     def compute_qkv(self, input):
         n = len(self.SU_qkv)
         x = input.reshape(-1, n).half()
-        xr = had.rotate(x, hadK=self.had_left_qkv_T, K=self.hidden_K, su=self.SU_qkv, post_scale=1.0 / self.scale)
         layers, wscales, blocks = self._qkv_layout()
-        out = _scaled_linears(layers, xr, wscales, self.scale).half()
+        out = _rotated_linears(layers, x, self.SU_qkv, self.had_left_qkv_T, self.hidden_K, wscales, self.scale).half()
         parts = dict(zip([b[0] for b in blocks], out.split([b[1] for b in blocks], dim=-1)))
         lead = input.shape[:-1]
         return (parts["q"].reshape(*lead, n), parts["k"].reshape(*lead, self.kv_out),
@@ -220,8 +233,8 @@ class IncoherentSdpaAttention(nn.Module):
     def compute_o(self, input):
         n = len(self.SU_o)
         x = input.reshape(-1, n).half()
-        xr = had.rotate(x, hadK=self.had_left_o_T, K=self.hidden_K, su=self.SU_o, post_scale=1.0 / self.scale)
-        return _scaled_linears([self.o_proj], xr, [self.Wscale_o], self.scale).half().view(*input.shape[:-1], n)
+        out = _rotated_linears([self.o_proj], x, self.SU_o, self.had_left_o_T, self.hidden_K, [self.Wscale_o], self.scale)
+        return out.half().view(*input.shape[:-1], n)
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
                 output_attentions=False, use_cache=False, cache_position=None, position_embeddings=None, **kwargs):

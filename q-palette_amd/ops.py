@@ -258,16 +258,35 @@ def _wscale_arg(wscales, j, m):
     return w.data_ptr()
 
 
+def _rot_args(x_rot, xh, k):
+    """x_rot = (su or None, post_scale): the kernel rotates x itself (C-ABI x_had).  -> (x_had, x_post, x_su ptr)"""
+    if x_rot is None:
+        return 0, 1.0, None
+    su, post = x_rot
+    _chk(bool(nat.lib().qpal_can_fuse_rotation(xh.shape[0], k)),
+         f"the rotation cannot be fused for batch {xh.shape[0]}, k = {k} (use hadamard.rotate first)")
+    if su is not None:
+        _chk(su.is_cuda and su.is_contiguous() and su.dtype == torch.float16 and su.numel() == k,
+             f"x_rot sign vector must be a contiguous fp16 CUDA vector of {k} elements")
+    return 1, float(post), (su.data_ptr() if su is not None else None)
+
+
+def can_fuse_rotation(n, k):
+    return bool(nat.lib().qpal_can_fuse_rotation(int(n), int(k)))
+
+
 def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=False, prezero=None, wscales=None,
-                   oscale=1.0):
+                   oscale=1.0, x_rot=None):
     """Several TCQ GEMVs of one codec and one input in ONE launch (C-ABI qpal_tcq_gemv_multi).
     streams: list of (c1, c2_or_None, tlut, m); x: [n, k].  Returns the list of fp32 [n, m] outputs.
     outs: write into these tensors (outs_zeroed: they are all zeros already); prezero: a tensor this launch
     also zeroes for a later split-K launch on the same stream.
-    wscales / oscale: fused epilogue out = acc * wscales[j][row] * oscale (the incoherent wrappers' Wscale * scale)."""
+    wscales / oscale: fused epilogue out = acc * wscales[j][row] * oscale (the incoherent wrappers' Wscale * scale).
+    x_rot = (su, post): x is the un-rotated input; the kernel stages fp16(fp16(H (x * su) / sqrt(k)) * post) itself."""
     n, k = x.shape
     _chk(1 <= n <= MAX_FUSED_BATCH, "batch size must be in 1..16")
     xh = _dev(x.to(torch.float16), "x")
+    had, xpost, xsu = _rot_args(x_rot, xh, k)
     jobs = (nat.TcqJob * len(streams))()
     results, keep = [], [xh]
     for j, (c1, c2, tlut, m) in enumerate(streams):
@@ -283,7 +302,7 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
         out = _out_arg(outs, j, n, m, x.device)
         jobs[j] = nat.TcqJob(out.data_ptr(), c1.data_ptr(), c2.data_ptr() if c2 is not None else None,
                              xh.data_ptr(), tl.data_ptr(), m, k, 1 if (outs is not None and outs_zeroed) else 0,
-                             _wscale_arg(wscales, j, m), float(oscale), _ldo(out, n, m))
+                             _wscale_arg(wscales, j, m), float(oscale), _ldo(out, n, m), had, xpost, xsu)
         results.append(out)
         keep += [c1, c2, tl]
     zp, zb = _prezero_args(prezero)
@@ -293,12 +312,14 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
     return results
 
 
-def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezero=None, wscales=None, oscale=1.0):
+def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezero=None, wscales=None, oscale=1.0,
+                      x_rot=None):
     """Several VQ/SQ (tensor-core packing) GEMVs of one codec and one input in ONE launch.
     layers: list of (qweight, lut, m); x: [n, k].  outs / outs_zeroed / prezero as in tcq_gemv_multi."""
     n, k = x.shape
     _chk(1 <= n <= MAX_FUSED_BATCH, "batch size must be in 1..16")
     xh = _dev(x.to(torch.float16), "x")
+    had, xpost, xsu = _rot_args(x_rot, xh, k)
     jobs = (nat.LutJob * len(layers))()
     results, keep = [], [xh]
     for j, (q, lut, m) in enumerate(layers):
@@ -306,7 +327,7 @@ def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezer
         out = _out_arg(outs, j, n, m, x.device)
         jobs[j] = nat.LutJob(out.data_ptr(), q.data_ptr(), xh.data_ptr(), cb.data_ptr(), m, k,
                              1 if (outs is not None and outs_zeroed) else 0, _wscale_arg(wscales, j, m), float(oscale),
-                             _ldo(out, n, m))
+                             _ldo(out, n, m), had, xpost, xsu)
         results.append(out)
         keep += [q, cb]
     zp, zb = _prezero_args(prezero)

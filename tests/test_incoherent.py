@@ -274,9 +274,10 @@ def _close(got, want, mag, what):
 @gpu
 @pytest.mark.parametrize("qstr,merge", [("tcq_4_0_1", False), ("tcq_4_0_1", True), ("tcomb_5_6_0.5_0_1", True),
                                         ("ldlq_2_7_0_1", False)])
-@pytest.mark.parametrize("n", [1, 3])
-def test_incoherent_mlp_vs_oracle(qp, oracle, qstr, merge, n):
-    cfg = _cfg()
+@pytest.mark.parametrize("n,hidden", [(1, 1024), (3, 1024), (1, 2048), (3, 2048)])
+def test_incoherent_mlp_vs_oracle(qp, oracle, qstr, merge, n, hidden):
+    # hidden = 2048: the up|gate rotation runs inside the GEMV launch (x_rot); 1024: separate qpal_hadamard launch
+    cfg = _cfg(hidden=hidden)
     H, I = cfg.hidden_size, cfg.intermediate_size
     up, gate, down = _info(qp, H, I, qstr, 11), _info(qp, H, I, qstr, 12), _info(qp, I, H, qstr, 13)
     mlp = qp.IncoherentMLP.gen_layer_from_info(cfg, up, gate, down, merge_ug=merge).cuda()
@@ -398,3 +399,36 @@ def test_gemv_epilogue_scale_and_strided_out(qp, oracle):
     (y,) = qp.multi_gemv([layer], torch.from_numpy(x).cuda(), oscale=0.5)
     acc, mag = _lin(oracle, info, x.astype(np.float64))
     assert np.all(np.abs(y.cpu().numpy() - acc * 0.5) <= 1e-5 * mag + 1e-30)
+
+
+@gpu
+@pytest.mark.parametrize("k,n", [(2048, 1), (2048, 4), (2048, 5), (4096, 1), (4096, 2), (4096, 3)])
+def test_fused_rotation_equals_separate_launch(qp, oracle, k, n):
+    """x_rot of the GEMV entry points (rotation inside the kernel's x staging) vs qpal_hadamard + plain GEMV: the
+    same transform code on the same data -> identical staged x -> bit-identical outputs; plus the oracle bound."""
+    rng = np.random.default_rng(k + n)
+    x = rng.standard_normal((n, k)).astype(np.float16)
+    su = _signs(rng, k)
+    xd, sud = torch.from_numpy(x).cuda(), torch.from_numpy(su).cuda()
+    xr = qp.hadamard.rotate(xd, su=sud, post_scale=1 / 64)
+    want_x = oi.left_input(x, su, None, 64.0)
+    _assert_ulp(xr.cpu().numpy(), want_x)
+    for qstr, ms in (("tcq_4_0_1", (512, 256)), ("tcomb_6_7_0.5_0_1", (512,)), ("ldlq_2_8_0_1", (256, 256, 128))):
+        infos = [_info(qp, k, m, qstr, 60 + i) for i, m in enumerate(ms)]
+        layers = [qp.make_linear(i).cuda() for i in infos]
+        qp.share_codebooks(layers)
+        assert qp.linear.rotation_fusable(layers, n)
+        ws = [i["Wscale"].cuda() for i in infos]
+        sep = qp.multi_gemv(layers, xr, wscales=ws, oscale=64.0)
+        fused = qp.multi_gemv(layers, xd, wscales=ws, oscale=64.0, x_rot=(sud, 1 / 64))
+        for a, b, info in zip(sep, fused, infos):
+            assert torch.equal(a, b), qstr
+            acc, mag = _lin(oracle, info, xr.cpu().numpy().astype(np.float64))
+            wsn = info["Wscale"].numpy().astype(np.float64) * 64.0
+            assert np.all(np.abs(b.cpu().numpy() - acc * wsn) <= 1e-5 * mag * wsn + 1e-30)
+    # not fusable: SIMT packing, k without the fast transform, batch beyond the LDS staging
+    assert not qp.ops.can_fuse_rotation(1, 14336) and not qp.ops.can_fuse_rotation(8, 4096)
+    assert not qp.ops.can_fuse_rotation(1, 8192) and not qp.ops.can_fuse_rotation(1, 1024)
+    with pytest.raises(RuntimeError):
+        qp.multi_gemv([qp.make_linear(_info(qp, 1024, 256, "tcq_4_0_1", 70)).cuda()],
+                      torch.zeros(1, 1024, dtype=torch.float16, device="cuda"), x_rot=(None, 1.0))
