@@ -143,6 +143,20 @@ int qpal_tc_to_simt(void *dst_simt, const void *src_tc, int m, int k, int bits, 
 int qpal_hadamard(void *out_f16, const void *in, const void *su, const void *sv, const void *hadk,
                   int rows, int n, int hd, int K, int in_mode, int round_mid, float post_scale, void *stream);
 
+/* Host-side encoders of the packed formats (plain CPU code; HOST pointers; no GPU involved): what a quantiser or a
+ * checkpoint converter calls once per layer.  Bit for bit the reference's packers:
+ *   qpal_pack_tcq         Qidxs int32 [m][k/2] (state t of tile (tr, tc) at [16 tr + t/8][8 tc + t%8]) -> int16
+ *                         [(m/16)(k/16)][8 KV]: pack_trellis + nibble permutation, lib/codebook/bitshift.py:296-329,
+ *                         lib/quantizer/tcq_quant.py:47-60.  QPAL_E_PARAM if the states are not a tail-biting walk.
+ *   qpal_pack_tcq_states  the same from uint16 [tiles][128] tile-major states
+ *   qpal_pack_lut_tc      indices int32 [m][k/vec] -> int32 [m][bits k/32/vec]: pack_qweight, lib/quantizer/quant_op.py:89-162
+ *   qpal_pack_lut_simt    indices -> uint32 [m][bits k/32/vec]: pack_qweight_sq_simt / pack_qweight_vq_simt,
+ *                         lib/quantizer/quant_op.py:69-87 (numba loops of lib/quantizer/pack_op.py:288-335)            */
+int qpal_pack_tcq(void *dst, const int32_t *qidxs, int m, int k, int KV);
+int qpal_pack_tcq_states(void *dst, const uint16_t *states, int m, int k, int KV);
+int qpal_pack_lut_tc(void *dst, const int32_t *idx, int m, int k, int bits, int vec);
+int qpal_pack_lut_simt(void *dst, const int32_t *idx, int m, int k, int bits, int vec);
+
 /* 1 if the GEMV entry points can apply the rotation themselves (x_had): k in {2048, 4096} and the batch small
  * enough for x to be staged in LDS; 0 otherwise (then call qpal_hadamard first). */
 int qpal_can_fuse_rotation(int n, int k);

@@ -9,6 +9,7 @@ Layout:
                    (lib/utils/mem_op.py:2-307)
   hadamard.py      get_hadK (generated Paley factors), matmul_hadU*_cuda, the one-launch `rotate` (lib/utils/matmul_had.py)
   linear/incoherent_linear.py  IncoherentLinear / IncoherentMLP / IncoherentSdpaAttention (lib/linear/incoherent_linear.py)
+  packers.py       pack_trellis / pack_qweight / pack_qweight_{sq,vq}_simt on the C-ABI's host-side encoders
   shard.py         row-sharding of packed layers across GPUs (torch.distributed / RCCL)
 
 There is deliberately no CPU implementation here: the CPU restatement lives in /oracle and is test
@@ -19,6 +20,7 @@ from . import ops  # noqa: F401
 from . import mem_op  # noqa: F401
 from . import shard  # noqa: F401
 from . import hadamard  # noqa: F401
+from . import packers  # noqa: F401
 from .linear import (  # noqa: F401
     IncoherentLinear,
     IncoherentMLP,

@@ -39,6 +39,10 @@ _SIGNATURES = {
     "qpal_lut_simt_dequant": [_P, _P, _P, _I, _I, _I, _I, _P],
     "qpal_tc_to_simt": [_P, _P, _I, _I, _I, _I, _P],
     "qpal_can_fuse_rotation": [_I, _I],
+    "qpal_pack_tcq": [_P, _P, _I, _I, _I],
+    "qpal_pack_tcq_states": [_P, _P, _I, _I, _I],
+    "qpal_pack_lut_tc": [_P, _P, _I, _I, _I, _I],
+    "qpal_pack_lut_simt": [_P, _P, _I, _I, _I, _I],
     "qpal_hadamard": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
 }
 
