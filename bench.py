@@ -66,6 +66,8 @@ def parse_args():
                     help="run every projection group inside the reference's incoherence wrapper: sign flip + Hadamard + "
                          "1/scale before (one qpal_hadamard launch, SwiGLU fused for down_proj), Wscale*scale fused into "
                          "the GEMV epilogue (SURVEY §8 f-1)")
+    ap.add_argument("--no-incoherent-extra", action="store_true",
+                    help="skip the second figure (token with the incoherence wrapper) of the default run")
     ap.add_argument("--no-fuse-rotation", action="store_true",
                     help="--incoherent: always rotate in a launch of its own (default: inside the GEMV where k allows)")
     ap.add_argument("--layers", type=int, default=0, help="override the number of layers (0 = model's)")
@@ -227,12 +229,12 @@ def main():
     main_stream = torch.cuda.Stream(device)
     side = [torch.cuda.Stream(device) for _ in range(2)] if args.streams >= 3 else []
 
-    inc = None
-    if args.incoherent:
+    had = qp.hadamard
+    inc = []
+
+    def build_incoherent_state():
         assert args.launch == "multi" and gather is None, "--incoherent runs on the multi-job launch path"
-        had = qp.hadamard
         gen = torch.Generator(device=device).manual_seed(4321)
-        inc = []
         for groups in layers:
             per = []
             for grp in groups:
@@ -244,6 +246,9 @@ def main():
                     "wscale": [(0.01 + 0.02 * torch.rand(m.out_features, device=device, generator=gen)).half()
                                for m, _, _ in grp]})
             inc.append(per)
+
+    if args.incoherent:
+        build_incoherent_state()
 
     nrot = [0]  # rotation launches of one token (beyond the SwiGLU one of every layer)
 
@@ -288,7 +293,7 @@ def main():
         return outs
 
     def token():
-        if inc is not None:
+        if args.incoherent:
             return token_incoherent()
         outs = []
         for groups in layers:
@@ -363,6 +368,33 @@ def main():
         wall = time.perf_counter() - t0
         dev_s = e0.elapsed_time(e1) / 1e3
 
+    # Second figure (N = 1 only, after the timed region of the headline): the same token with every projection group
+    # inside the reference's incoherence wrapper (rotation + scales), i.e. what an IncoherentMLP / attention forward costs.
+    extra = None
+    if world == 1 and not args.incoherent and not args.no_incoherent_extra and args.launch == "multi" and graph is not None:
+        try:
+            build_incoherent_state()
+            with torch.cuda.stream(main_stream):
+                token_incoherent()
+                torch.cuda.synchronize()
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, stream=main_stream):
+                    token_incoherent()
+                for _ in range(args.warmup):
+                    g2.replay()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    g2.replay()
+                torch.cuda.synchronize()
+                w2 = time.perf_counter() - t1
+            extra = {"value": args.steps * n / w2, "unit": "tokens/s", "ms_per_step": w2 / args.steps * 1e3,
+                     "rotation_launches_per_token": nlayers + nrot[0],
+                     "what": "same token, every projection group behind sign flip + Hadamard + scales (rotation fused into "
+                             "the GEMV x staging for k = 4096, one SwiGLU+rotation launch per layer for down_proj)"}
+        except Exception as exc:  # the headline line must not depend on this leg
+            extra = {"error": repr(exc)}
+
     if world > 1:
         t = torch.tensor([wall, dev_s], device=device if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -397,6 +429,8 @@ def main():
                      "algorithmic_bytes_per_launch": abytes / (world if tp else 1) / nlaunch,
                      "avg_launch_us": t_token / nlaunch * 1e6},
     }
+    if extra is not None:
+        out["with_incoherence_wrapper"] = extra
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(qp, layers, n, args.cpu_seconds)
