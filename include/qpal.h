@@ -157,8 +157,8 @@ int qpal_pack_tcq_states(void *dst, const uint16_t *states, int m, int k, int KV
 int qpal_pack_lut_tc(void *dst, const int32_t *idx, int m, int k, int bits, int vec);
 int qpal_pack_lut_simt(void *dst, const int32_t *idx, int m, int k, int bits, int vec);
 
-/* 1 if the GEMV entry points can apply the rotation themselves (x_had): k in {2048, 4096} and the batch small
- * enough for x to be staged in LDS; 0 otherwise (then call qpal_hadamard first). */
+/* 1 if the GEMV entry points can apply the rotation themselves (x_had): k in {2048, 4096} at batch 1 (the
+ * decode case); 0 otherwise (then call qpal_hadamard first). */
 int qpal_can_fuse_rotation(int n, int k);
 
 const char *qpal_error_string(int code);

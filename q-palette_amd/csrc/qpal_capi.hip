@@ -43,7 +43,8 @@ int x_fits_lds(int n, int k) {
 }
 
 // (k = 8192 would need the 8-row-tile transform: its registers do not fit the GEMV kernel's 128-VGPR budget)
-bool rot_ok(int n, int k) { return (k == 2048 || k == 4096) && x_fits_lds(n, k); }
+// and batch 1 only: the workgroup-wide transform needs 16 KiB of LDS beside x (larger batches: qpal_hadamard first)
+bool rot_ok(int n, int k) { return n == 1 && (k == 2048 || k == 4096) && x_fits_lds(n, k); }
 
 // x_had of a job -> kernel parameters; QPAL_E_SHAPE where the fused rotation is not available
 int set_rotation(TcParams &p, int x_had, const void *x_su, float x_post, int n, int k) {

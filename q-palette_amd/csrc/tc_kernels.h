@@ -395,9 +395,10 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
     for (int i = 0; i < kMaxJobs; i++) ie[i] = mp.item_end[i];
     TcParams p = mp.job[0];
     const int total_items = ie[kMaxJobs - 1];
-    if (mp.zero_chunks > 0) {  // pre-zero a buffer for a later split-K launch on this stream
-        for (int i = blockIdx.x * 1024 + tid; i < mp.zero_chunks; i += gridDim.x * 1024) mp.zero[i] = u32x4{0u, 0u, 0u, 0u};
-    }
+    // Pin job 0's loads next to the item table's: left alone, the compiler requests job 0 only inside the loop, after
+    // it has waited for the item table — two kernel-argument round trips on the critical path instead of one.
+    asm volatile("" ::"s"(p.c1), "s"(p.c2), "s"(p.x), "s"(p.tab), "s"(p.nrows), "s"(p.nsc1), "s"(p.log2_wpr), "s"(p.sk),
+                 "s"(p.out), "s"(ie[0]), "s"(p.wscale), "s"(p.base2));
     for (int gitem = blockIdx.x; gitem < total_items; gitem += gridDim.x) {
         int j = 0, item_begin = 0;
 #pragma unroll
@@ -431,7 +432,9 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
         const bool live = sr < p.nrows;
         // per-row output scale of the epilogue: requested now, consumed after the steps (a load issued there
         // would put a whole memory round trip at the end of the kernel)
-        uint16_t wraw = 0x3C00;  // 1.0
+        uint32_t wraw;
+        asm volatile("" : "=v"(wraw));  // "no value yet": a constant here would be merged with the load at the join
+                                        // below, and the merge waits for the load on the spot
         if (p.wscale && tid < (32 << log2_rpw) && (rg << log2_rpw) + (tid >> 5) < p.nrows)
             wraw = p.wscale[((rg << log2_rpw) + (tid >> 5)) * 32 + (tid & 31)];
         const int c = ks * wpr + wr;
@@ -455,37 +458,45 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
         // first step's weights are in flight while x and the codebook image are (re)staged
         if (on2) load_step_w<CB::NW>(sv2, s0, lane, w.b);
         else load_step_w<C1::NW>(sv1, s0, lane, w.a);
+        if (gitem == (int)blockIdx.x && mp.zero_chunks > 0) {  // pre-zero a buffer for a later split-K launch on this stream
+            for (int i = blockIdx.x * 1024 + tid; i < mp.zero_chunks; i += gridDim.x * 1024) mp.zero[i] = u32x4{0u, 0u, 0u, 0u};
+        }
         QPAL_STAMP(1);
         if (p.tab != cur_tab || (x_lds && p.x != cur_x)) {  // workgroup-uniform
-            [[maybe_unused]] int build_first = 0;  // ROT: waves below this one rotate x, the others build the image
             if (x_lds && p.x != cur_x) {
                 const int total = p.n * p.k;  // multiple of 8 halves
                 if (ROT && p.x_rot) {
                   if constexpr (ROT) {
-                    // Incoherence rotation fused into the staging: wave quad g transforms batch rows g, g + nq, ...
-                    // straight from global memory into the LDS copy (wht64.h: matrix pipe, no barrier inside) while
-                    // the other waves build the codebook image.  (Staging x * su in LDS first and rotating from
-                    // there — one global read per workgroup instead of four — measured slower: two more barriers.)
-                    const int nq = p.n < 3 ? p.n : 3;  // quads that rotate (at least one quad keeps building)
-                    build_first = 4 * nq;
-                    if (wave < build_first) {
-                        for (int b = wave >> 2; b < p.n; b += nq) {
-                            const uint16_t *xrow = p.x + (long)b * p.k;
-                            uint16_t *dst = xs + b * p.k;
-                            auto load_a = [&](int t, int kc) {
-                                const int off = (16 * t + (lane & 15)) * 64 + 32 * kc + 8 * (lane >> 4);
-                                wht_half8 h = *reinterpret_cast<const wht_half8 *>(xrow + off);
-                                if (p.x_su) h = h * *reinterpret_cast<const wht_half8 *>(p.x_su + off);
-                                return h;
-                            };
-                            auto store = [&](int, int, int i, float v) {
-                                dst[i] = __builtin_bit_cast(uint16_t, (_Float16)((float)(_Float16)v * p.x_post));
-                            };
-                            if (p.x_rot == 4) wht64_quad<4, 4>(wave & 3, lane, p.x_pre, load_a, store);
-                            else wht64_quad<2, 2>(wave & 3, lane, p.x_pre, load_a, store);
-                        }
-                        if (tid < 32) xs[total + tid] = 0;
+                    // Incoherence rotation fused into the staging (wht64.h: Walsh-Hadamard transform on the matrix pipe).
+                    auto store_row = [&](uint16_t *dst) {
+                        return [=](int, int, int i, float v) {
+                            dst[i] = __builtin_bit_cast(uint16_t, (_Float16)((float)(_Float16)v * p.x_post));
+                        };
+                    };
+                    auto load_row = [&](const uint16_t *xrow) {
+                        return [=](int t, int kc) {
+                            const int off = (16 * t + (lane & 15)) * 64 + 32 * kc + 8 * (lane >> 4);
+                            wht_half8 h = *reinterpret_cast<const wht_half8 *>(xrow + off);
+                            if (p.x_su) h = h * *reinterpret_cast<const wht_half8 *>(p.x_su + off);
+                            return h;
+                        };
+                    };
+                    // Batch 1 only (the host refuses x_rot otherwise): the transform is spread over all 16 waves in two
+                    // stages around one extra barrier — x is read once per workgroup and no wave runs more than ~100
+                    // instructions; the codebook image is built by the waves that have no stage-1 tile.
+                    // (Alternatives measured slower: one wave quad rotating straight from global memory, +2.0 us per
+                    // launch; x * su staged in LDS first, two more barriers.)
+                    wht_float4 *d1buf = reinterpret_cast<wht_float4 *>(xs + ((total + 32 + 7) & ~7));  // <= 16 KiB
+                    if (p.x_rot == 4) wht64_wg_stage1<4>(wave, lane, d1buf, load_row(p.x));
+                    else wht64_wg_stage1<2>(wave, lane, d1buf, load_row(p.x));
+                    if (p.tab != cur_tab) {
+                        if (wave >= p.x_rot) C1::build(lut, p.tab, tid - 64 * p.x_rot, 1024 - 64 * p.x_rot);
+                        cur_tab = p.tab;
                     }
+                    if (tid < 32) xs[total + tid] = 0;
+                    __syncthreads();
+                    if (p.x_rot == 4) wht64_wg_stage2<4>(wave, lane, p.x_pre, d1buf, store_row(xs));
+                    else wht64_wg_stage2<2>(wave, lane, p.x_pre, d1buf, store_row(xs));
                   }
                 } else {
                     for (int i = tid * 8; i < total + 32; i += 1024 * 8) {
@@ -497,7 +508,7 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
                 cur_x = p.x;
             }
             if (p.tab != cur_tab) {
-                if (wave >= build_first) C1::build(lut, p.tab, tid - 64 * build_first, 1024 - 64 * build_first);
+                C1::build(lut, p.tab, tid, 1024);
                 cur_tab = p.tab;
             }
             QPAL_STAMP(2);
@@ -548,7 +559,7 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
             const int srow = (rg << log2_rpw) + rl;
             if (srow < p.nrows) {
                 // the incoherent wrappers' `* Wscale * scale`, fused
-                const float osc = p.oscale * (float)__builtin_bit_cast(_Float16, wraw);
+                const float osc = p.wscale ? p.oscale * (float)__builtin_bit_cast(_Float16, (uint16_t)wraw) : p.oscale;
                 for (int b = 0; b < p.n; b++) {
                     float v = 0.f;
                     for (int qq = 0; qq < wpr; qq++) v += red[(((rl << p.log2_wpr) + qq) * p.n + b) * 32 + r];

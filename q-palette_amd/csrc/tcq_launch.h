@@ -1,0 +1,54 @@
+// One TCQ GEMV launch (+ the QPAL_STAMPS diagnostic: per-phase in-kernel time stamps of the first launch per shape).
+#pragma once
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "tcq_kernels_api.h"
+
+namespace qpal {
+
+template <int S, int KV1, int KV2, int NBG, bool ROT = false>
+static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
+    [[maybe_unused]] const TcParams &p = mp.job[0];
+    using C1 = TcqCodec<S, KV1>;
+    using C2 = std::conditional_t<KV2 == 0, void, TcqCodec<S, KV2 == 0 ? KV1 : KV2>>;
+#ifdef QPAL_STAMPS
+    // diagnostic build: stamp the first launch of every grid size and print the per-phase shares
+    static int seen[8] = {0};
+    static int nseen = 0;
+    bool fresh = true;
+    for (int i = 0; i < nseen; i++) fresh = fresh && seen[i] != grid * 131 + p.k;
+    if (fresh && nseen < 8) {
+        seen[nseen++] = grid * 131 + p.k;
+        TcParams q = p;
+        unsigned long long *d = nullptr;
+        const size_t nb = (size_t)grid * 16 * 8 * sizeof(unsigned long long);
+        hipMalloc(&d, nb);
+        hipMemset(d, 0, nb);
+        q.dbg = d;
+        for (int rep = 0; rep < 3; rep++) { TcMultiParams mq = mp; mq.job[0] = q; hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(1024), 0, stream, mq); }
+        hipDeviceSynchronize();
+        unsigned long long *h = (unsigned long long *)malloc(nb);
+        hipMemcpy(h, d, nb, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t7 = 0;
+        double ph[8] = {0};
+        for (int w = 0; w < grid * 16; w++) {
+            if (h[w * 8] < t0) t0 = h[w * 8];
+            if (h[w * 8 + 7] > t7) t7 = h[w * 8 + 7];
+            for (int i = 1; i < 8; i++) ph[i] += (double)(h[w * 8 + i] - h[w * 8 + i - 1]);
+        }
+        printf("[stamps] grid %d m %d k %d wpr %d sk %d: span %.2f us (100MHz ticks); mean per-wave phase us:", grid, p.nrows * 32, p.k, 1 << p.log2_wpr, p.sk,
+               (t7 - t0) / 100.0);
+        const char *nm[8] = {"", "issue-w", "x+lut", "barrier", "steps", "xor-red", "barrier2", "final"};
+        for (int i = 1; i < 8; i++) printf(" %s %.2f", nm[i], ph[i] / (grid * 16) / 100.0);
+        printf("\n");
+        free(h);
+        hipFree(d);
+    }
+#endif
+    hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(1024), 0, stream, mp);
+    return (int)hipGetLastError();
+}
+
+
+}  // namespace qpal

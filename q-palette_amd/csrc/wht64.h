@@ -119,4 +119,68 @@ __device__ __forceinline__ void wht64_quad(int ct, int lane, float scale, LoadA 
     }
 }
 
+
+// The same transform spread over a whole workgroup (used where the other waves would only wait: the GEMV prologue at
+// batch 1).  Stage 1: wave t < RT loads row tile t ONCE and produces its four column tiles (8 MFMAs) into `d1buf`
+// ([RT][4][64] float4 = RT KiB * 4 in LDS); after the caller's barrier, wave w < 4 RT = (t' = w >> 2, ct = w & 3) forms
+// one output tile (2 NKC MFMAs).  x is read once per workgroup instead of four times, and no wave runs more than
+// ~100 instructions.  Call wht64_wg_stage1, __syncthreads(), wht64_wg_stage2.
+template <int RT, class LoadA>
+__device__ __forceinline__ void wht64_wg_stage1(int wave, int lane, wht_float4 *d1buf, LoadA &&load_a) {
+    if (wave >= RT) return;
+    const uint32_t q = lane >> 4, j = lane & 15;
+    uint32_t neg = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < 8; e++) neg |= wht_parity(e & (j & 7u)) << e;
+    const u32x4 base = wht_signs(neg);
+    const wht_half8 a0 = load_a(wave, 0), a1 = load_a(wave, 1);
+#pragma unroll
+    for (uint32_t ct = 0; ct < 4; ct++) {
+        const uint32_t f0 = ((q & 1u) & (j >> 3)) ^ ((q >> 1) & (ct & 1u)), f1 = f0 ^ ((ct >> 1) & 1u);
+        wht_float4 acc{0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, __builtin_bit_cast(wht_half8, wht_flip(base, f0, f0)), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(wht_half8, wht_flip(base, f1, f1)), acc, 0, 0, 0);
+        d1buf[(wave * 4 + ct) * 64 + lane] = acc;
+    }
+}
+
+template <int RT, class Store>
+__device__ __forceinline__ void wht64_wg_stage2(int wave, int lane, float scale, const wht_float4 *d1buf, Store &&store) {
+    if (wave >= 4 * RT) return;
+    const int tp = wave >> 2, ct = wave & 3;
+    const uint32_t q = lane >> 4, r = lane & 15;
+    constexpr uint32_t M = 0x80008000u;
+    constexpr int NKC = (RT + 1) / 2;
+    uint32_t neg2 = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < 8; e++) neg2 |= wht_parity((r & 3u) & (e & 3u)) << e;
+    const uint32_t g_lane = wht_parity((r >> 2) & q);
+    const u32x4 a_tp = wht_flip(wht_signs(neg2), g_lane, g_lane ^ ((uint32_t)tp & 1u));
+    wht_float4 acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < NKC; kc++) {
+        wht_half8 bh, bl;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int t = 2 * kc + half;
+            wht_float4 d{0.f, 0.f, 0.f, 0.f};
+            if (t < RT) d = d1buf[(t * 4 + ct) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float v = d[i] * 0.125f;
+                const _Float16 hi = (_Float16)v;
+                bh[4 * half + i] = hi;
+                bl[4 * half + i] = (_Float16)(v - (float)hi);
+            }
+        }
+        u32x4 a = a_tp;
+        if (__builtin_popcount((tp >> 1) & kc) & 1) a = u32x4{a[0] ^ M, a[1] ^ M, a[2] ^ M, a[3] ^ M};
+        const wht_half8 ah = __builtin_bit_cast(wht_half8, a);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) store(tp, i, (16 * tp + 4 * (int)q + i) * 64 + 16 * ct + (int)r, acc[i] * (8.0f * scale));
+}
+
 }  // namespace qpal

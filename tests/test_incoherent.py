@@ -276,7 +276,7 @@ def _close(got, want, mag, what):
                                         ("ldlq_2_7_0_1", False)])
 @pytest.mark.parametrize("n,hidden", [(1, 1024), (3, 1024), (1, 2048), (3, 2048)])
 def test_incoherent_mlp_vs_oracle(qp, oracle, qstr, merge, n, hidden):
-    # hidden = 2048: the up|gate rotation runs inside the GEMV launch (x_rot); 1024: separate qpal_hadamard launch
+    # hidden = 2048, n = 1: the up|gate rotation runs inside the GEMV launch (x_rot); else: separate qpal_hadamard launch
     cfg = _cfg(hidden=hidden)
     H, I = cfg.hidden_size, cfg.intermediate_size
     up, gate, down = _info(qp, H, I, qstr, 11), _info(qp, H, I, qstr, 12), _info(qp, I, H, qstr, 13)
@@ -402,8 +402,8 @@ def test_gemv_epilogue_scale_and_strided_out(qp, oracle):
 
 
 @gpu
-@pytest.mark.parametrize("k,n", [(2048, 1), (2048, 4), (2048, 5), (4096, 1), (4096, 2), (4096, 3)])
-def test_fused_rotation_equals_separate_launch(qp, oracle, k, n):
+@pytest.mark.parametrize("k", [2048, 4096])
+def test_fused_rotation_equals_separate_launch(qp, oracle, k, n=1):
     """x_rot of the GEMV entry points (rotation inside the kernel's x staging) vs qpal_hadamard + plain GEMV: the
     same transform code on the same data -> identical staged x -> bit-identical outputs; plus the oracle bound."""
     rng = np.random.default_rng(k + n)
@@ -427,7 +427,7 @@ def test_fused_rotation_equals_separate_launch(qp, oracle, k, n):
             wsn = info["Wscale"].numpy().astype(np.float64) * 64.0
             assert np.all(np.abs(b.cpu().numpy() - acc * wsn) <= 1e-5 * mag * wsn + 1e-30)
     # not fusable: SIMT packing, k without the fast transform, batch beyond the LDS staging
-    assert not qp.ops.can_fuse_rotation(1, 14336) and not qp.ops.can_fuse_rotation(8, 4096)
+    assert not qp.ops.can_fuse_rotation(1, 14336) and not qp.ops.can_fuse_rotation(2, 4096)
     assert not qp.ops.can_fuse_rotation(1, 8192) and not qp.ops.can_fuse_rotation(1, 1024)
     with pytest.raises(RuntimeError):
         qp.multi_gemv([qp.make_linear(_info(qp, 1024, 256, "tcq_4_0_1", 70)).cuda()],
