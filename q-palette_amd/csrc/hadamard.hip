@@ -337,7 +337,76 @@ __global__ __launch_bounds__(256) void had_mfma_kernel(HadParams p) {
         });
 }
 
+// Second half of the two-launch K > 1 path: out[j][c] <- fp16(fp16(sum_i hadK[j][i] t[i][c]) * post [* sv]) IN PLACE, t = the
+// fp16 segment transforms the first launch left in `out`.  One wave per 16-column tile (it reads and writes only its
+// own columns, so the update is race-free across waves and workgroups); K <= 32.
+__global__ __launch_bounds__(256) void hadk_mix_kernel(HadParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, c16 = lane & 15;
+    const int P = 1 << p.logP;
+    const int tiles = P >> 4;                      // column tiles per block
+    const int tile = blockIdx.x * 4 + wave;        // over rows * blocks * tiles
+    if (tile >= p.rows * (p.n / p.hd) * tiles) return;
+    const int ct = tile % tiles, bidx = tile / tiles;
+    uint16_t *blk = p.out + (long)bidx * p.hd;     // rows and blocks are contiguous: [rows][n / hd][hd]
+    const int c = (ct << 4) + c16;
+    uint16_t araw[2][8], traw[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int i = (q << 3) + e;
+        traw[e] = blk[(i < p.K ? i : p.K - 1) * P + c];
+    }
+#pragma unroll
+    for (int jt = 0; jt < 2; jt++) {
+        const int ja = (jt << 4) + c16;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int i = (q << 3) + e;
+            araw[jt][e] = p.hadk[(ja < p.K ? ja : p.K - 1) * p.K + (i < p.K ? i : p.K - 1)];
+        }
+    }
+    half8_t b;
+#pragma unroll
+    for (int e = 0; e < 8; e++) b[e] = (q << 3) + e < p.K ? __builtin_bit_cast(_Float16, traw[e]) : (_Float16)0.f;
+    const int col0 = (bidx % (p.n / p.hd)) * p.hd;
+#pragma unroll
+    for (int jt = 0; jt < 2; jt++) {
+        half8_t a;
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            a[e] = ((q << 3) + e < p.K && (jt << 4) + c16 < p.K) ? __builtin_bit_cast(_Float16, araw[jt][e]) : (_Float16)0.f;
+        float4_t acc{0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int j = (jt << 4) + (q << 2) + r;
+            if (j < p.K) {
+                float u = round_f16(acc[r]) * p.post_scale;
+                if (p.sv) u = round_f16(u) * h2f(p.sv[col0 + j * P + c]);
+                blk[j * P + c] = f2h(u);
+            }
+        }
+    }
+}
+
 int launch_hadamard(const HadParams &p, hipStream_t stream) {
+    if (p.K > 1 && p.K <= 32 && p.round_mid && p.logP >= 6 && p.hd > 4096) {
+        // Two launches instead of one workgroup: (1) every 2^p-segment as its own K = 1 transform on its own compute
+        // unit (scaled by the block's hd^-1/2, fp16 = the reference's intermediate), (2) hadK across the segments, in
+        // place.  The 14336-vector with SwiGLU: 12.4 us -> 2 short launches.  (One launch with the last-arriving
+        // workgroup doing step 2 needs device-scope fences: measured 18.7 us.)
+        HadParams a = p;
+        a.hd = 1 << p.logP;
+        a.K = 1;
+        a.post_scale = 1.0f;
+        a.sv = nullptr;
+        a.hadk = nullptr;
+        int rc = launch_hadamard(a, stream);
+        if (rc) return rc;
+        const int tiles = p.rows * (p.n / p.hd) * (a.hd >> 4);
+        hipLaunchKernelGGL(hadk_mix_kernel, dim3((tiles + 3) / 4), dim3(256), 0, stream, p);
+        return (int)hipGetLastError();
+    }
     if (p.K == 1 && p.in_mode == QPAL_IN_F16 && (p.hd == 1024 || p.hd == 2048 || p.hd == 4096)) {  // 8192: the butterflies win (measured)
         const int g = p.rows * (p.n / p.hd);
         if (p.hd == 1024) hipLaunchKernelGGL((had_mfma_kernel<1>), dim3(g), dim3(256), 0, stream, p);
