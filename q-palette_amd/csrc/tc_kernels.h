@@ -101,12 +101,14 @@ struct TcqCodec {
     template <int G>
     static constexpr int baseB() { return 16 * KV + G * L4; }
 
+    static constexpr int CHUNKS = LDS_DWORDS / 4;  // 16-byte chunks: conflict-free ds_write_b128
+    // image entry e (sign flag folded in) from the codebook in memory
+    static __device__ __forceinline__ uint32_t entry(const void *tab, int e) {
+        return static_cast<const uint32_t *>(tab)[e & ((1 << S) - 1)] ^ (((uint32_t)e >> S) << 15);
+    }
     static __device__ __forceinline__ void build(uint32_t *lds, const void *tab, int tid, int nthreads) {
-        const uint32_t *__restrict__ tlut = static_cast<const uint32_t *>(tab);
-        constexpr int CHUNKS = LDS_DWORDS / 4;  // 16-byte chunks: conflict-free ds_write_b128
         for (int c = tid; c < CHUNKS; c += nthreads) {
-            const int e = (c * 4) >> LOG2C;
-            const uint32_t v = tlut[e & ((1 << S) - 1)] ^ (((uint32_t)e >> S) << 15);
+            const uint32_t v = entry(tab, (c * 4) >> LOG2C);
             reinterpret_cast<u32x4 *>(lds)[c] = u32x4{v, v, v, v};
         }
     }
@@ -187,16 +189,17 @@ struct LutCodec {
     static constexpr int LDS_DWORDS = (1 << IDXBITS) * C;
     static_assert(LOG2C >= 2, "table build writes 4 copies per 16-byte chunk");
 
-    static __device__ __forceinline__ void build(uint32_t *lds, const void *tab, int tid, int nthreads) {
+    static constexpr int CHUNKS = LDS_DWORDS / 4;
+    static __device__ __forceinline__ uint32_t entry(const void *tab, int e) {
         const uint16_t *__restrict__ l16 = static_cast<const uint16_t *>(tab);
         const uint32_t *__restrict__ l32 = static_cast<const uint32_t *>(tab);
-        constexpr int CHUNKS = LDS_DWORDS / 4;
+        if constexpr (VEC == 2) return l32[e];
+        else if constexpr (PAIR) return (uint32_t)l16[e & ((1 << BITS) - 1)] | ((uint32_t)l16[e >> BITS] << 16);
+        else return l16[e];
+    }
+    static __device__ __forceinline__ void build(uint32_t *lds, const void *tab, int tid, int nthreads) {
         for (int c = tid; c < CHUNKS; c += nthreads) {
-            const int e = (c * 4) >> LOG2C;
-            uint32_t v;
-            if constexpr (VEC == 2) v = l32[e];
-            else if constexpr (PAIR) v = (uint32_t)l16[e & ((1 << BITS) - 1)] | ((uint32_t)l16[e >> BITS] << 16);
-            else v = l16[e];
+            const uint32_t v = entry(tab, (c * 4) >> LOG2C);
             reinterpret_cast<u32x4 *>(lds)[c] = u32x4{v, v, v, v};
         }
     }
@@ -371,8 +374,30 @@ constexpr int scratch_bytes() { return NBG == 1 ? kScratchBytes : 16 * 32 * 4 * 
 // All index arithmetic is shift/compare: the host passes the chunk partition (base/rem) precomputed.
 // ROT: instantiation that can rotate x while staging it (x_rot jobs); plain launches run the ROT = false kernels,
 // which do not carry that code (it costs ~3 % of a plain token when merely present: measured)
+// The leading scalar arguments are PRELOADED into SGPRs by the dispatcher (-mllvm -amdgpu-kernarg-preload-count, Makefile):
+// when every job of the launch reads the same activations and codebook (`early`), their loads are issued before the
+// kernel-argument block `mp` has even arrived (its fetch is a memory round trip on the critical path of a short kernel).
+struct TcEarly {
+    const uint16_t *x;  // shared by all jobs, staged in LDS
+    const void *tab;    // shared codebook
+    int n, k;           // x is [n][k]
+    int on;             // 0: jobs differ (or x does not fit LDS): everything comes from `mp` as before
+};
+
+// host: the launch qualifies when x is staged in LDS and every job has the same x, codebook and batch
+inline TcEarly early_args(const TcMultiParams &mp) {
+    const TcParams &a = mp.job[0];
+    TcEarly e{a.x, a.tab, a.n, a.k, a.x_lds && !a.x_rot && a.n <= 8 ? 1 : 0};
+    for (int j = 1; j < mp.njobs; j++) {
+        const TcParams &b = mp.job[j];
+        if (b.x != a.x || b.tab != a.tab || b.n != a.n || b.k != a.k || !b.x_lds || b.x_rot) e.on = 0;
+    }
+    return e;
+}
+
 template <class C1, class C2, int NBG, bool ROT = false>
-__global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
+__global__ __launch_bounds__(1024) void tc_gemv_kernel(const uint16_t *ex, const void *etab, int en, int ek, int eon,
+                                                       const TcMultiParams mp) {
     constexpr bool TWO = !std::is_void_v<C2>;
     using CB = std::conditional_t<TWO, C2, C1>;
     __shared__ __attribute__((aligned(16))) uint32_t lut[C1::LDS_DWORDS];
@@ -389,6 +414,29 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
     const void *cur_tab = nullptr;      // codebook whose image is in LDS
     const uint16_t *cur_x = nullptr;    // activations staged in LDS
     int cur_j = 0;
+    // early staging, part 1: request x and the codebook entries from the preloaded arguments (held in registers until
+    // the first weight loads have been issued)
+    constexpr bool kEarly = NBG == 1 && !ROT;
+    constexpr int NV = (C1::CHUNKS + 1023) / 1024;
+    [[maybe_unused]] u32x4 exr[2];
+    [[maybe_unused]] uint32_t etv[NV];
+    const bool early = kEarly && eon != 0;
+    if constexpr (kEarly) {
+        if (early) {
+            const int total = en * ek;
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int i = tid * 8 + r * 8192;
+                exr[r] = u32x4{0u, 0u, 0u, 0u};
+                if (i < total) exr[r] = *reinterpret_cast<const u32x4 *>(ex + i);
+            }
+#pragma unroll
+            for (int r = 0; r < NV; r++) {
+                const int c = tid + r * 1024;
+                etv[r] = C1::entry(etab, ((c < C1::CHUNKS ? c : 0) * 4) >> C1::LOG2C);
+            }
+        }
+    }
     // one scalar-load round trip for everything the first item needs: the item table and job 0
     int ie[kMaxJobs];
 #pragma unroll
@@ -458,6 +506,24 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const TcMultiParams mp) {
         // first step's weights are in flight while x and the codebook image are (re)staged
         if (on2) load_step_w<CB::NW>(sv2, s0, lane, w.b);
         else load_step_w<C1::NW>(sv1, s0, lane, w.a);
+        if constexpr (kEarly) {
+            if (early && gitem == (int)blockIdx.x) {  // early staging, part 2: registers -> LDS
+                const int total = en * ek;
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int i = tid * 8 + r * 8192;
+                    if (i < total + 32) *reinterpret_cast<u32x4 *>(xs + i) = exr[r];
+                }
+#pragma unroll
+                for (int r = 0; r < NV; r++) {
+                    const int c = tid + r * 1024;
+                    if (c < C1::CHUNKS) reinterpret_cast<u32x4 *>(lut)[c] = u32x4{etv[r], etv[r], etv[r], etv[r]};
+                }
+                cur_x = ex;
+                cur_tab = etab;
+                __syncthreads();
+            }
+        }
         if (gitem == (int)blockIdx.x && mp.zero_chunks > 0) {  // pre-zero a buffer for a later split-K launch on this stream
             for (int i = blockIdx.x * 1024 + tid; i < mp.zero_chunks; i += gridDim.x * 1024) mp.zero[i] = u32x4{0u, 0u, 0u, 0u};
         }

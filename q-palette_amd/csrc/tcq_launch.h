@@ -10,6 +10,7 @@ namespace qpal {
 template <int S, int KV1, int KV2, int NBG, bool ROT = false>
 static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
     [[maybe_unused]] const TcParams &p = mp.job[0];
+    const TcEarly e = early_args(mp);
     using C1 = TcqCodec<S, KV1>;
     using C2 = std::conditional_t<KV2 == 0, void, TcqCodec<S, KV2 == 0 ? KV1 : KV2>>;
 #ifdef QPAL_STAMPS
@@ -26,7 +27,7 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
         hipMalloc(&d, nb);
         hipMemset(d, 0, nb);
         q.dbg = d;
-        for (int rep = 0; rep < 3; rep++) { TcMultiParams mq = mp; mq.job[0] = q; hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(1024), 0, stream, mq); }
+        for (int rep = 0; rep < 3; rep++) { TcMultiParams mq = mp; mq.job[0] = q; hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(1024), 0, stream, e.x, e.tab, e.n, e.k, e.on, mq); }
         hipDeviceSynchronize();
         unsigned long long *h = (unsigned long long *)malloc(nb);
         hipMemcpy(h, d, nb, hipMemcpyDeviceToHost);
@@ -46,7 +47,7 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
         hipFree(d);
     }
 #endif
-    hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(1024), 0, stream, mp);
+    hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(1024), 0, stream, e.x, e.tab, e.n, e.k, e.on, mp);
     return (int)hipGetLastError();
 }
 
