@@ -259,7 +259,9 @@ template <int NW>
 __device__ __forceinline__ void load_step_w(const StreamView &sv, int step, int lane, uint32_t (&w)[NW]) {
     int sc = step * 4 + (lane >> 4);
     sc = sc < sv.nsc ? sc : sv.nsc - 1;
-    load_words_nt<NW>(sv.base + ((long)sc * 16 + (lane & 15)) * NW, w);
+    // 32-bit dword offset from the (wave-uniform) row base: scalar base + vector offset addressing, no 64-bit math
+    const uint32_t off = (uint32_t)sc * (16u * NW) + (uint32_t)(lane & 15) * NW;
+    load_words_nt<NW>(sv.base + off, w);
 }
 
 // Accumulators of one wave: NBG batch groups (8 batch rows each) x 4 row groups (msub*2 + jl).
