@@ -255,6 +255,31 @@ def test_multi_job_launch_equals_single_launches(qp):
                 assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
 
 
+def test_early_and_late_staging_agree(qp):
+    """When all jobs of a launch share x and the codebook tensor, the kernel stages them from PRELOADED kernel arguments
+    (before its argument block has arrived); with distinct codebook tensors of equal content it stages them the ordinary
+    way.  Same arithmetic either way: bit-identical outputs."""
+    k = 4096
+    for qstr, ms in (("tcomb_6_7_0.5_none_0.9", [1024, 512, 512]), ("ldlq_2_8_none_1.0", [512, 1024]), ("tcq_4_none_0.9", [256])):
+        layers = [qp.make_linear_from_info(qstr, qp.mem_op.dummy_linear_info(k, m, qstr, seed=m + i, codebook_seed=5)).cuda()
+                  for i, m in enumerate(ms)]
+        for n in (1, 2, 8, 11):
+            x = torch.randn(n, k, generator=torch.Generator().manual_seed(n)).cuda()
+            assert qp.share_codebooks(layers) == 1          # one tensor -> early staging (n <= 8)
+            shared = [y.clone() for y in qp.multi_gemv(layers, x)]
+            for layer in layers:                            # equal values, distinct tensors -> ordinary staging
+                name = "tlut" if hasattr(layer, "tlut") else "lut"
+                t = getattr(layer, name)
+                if isinstance(t, torch.nn.Parameter):
+                    t.data = t.data.clone()
+                else:
+                    setattr(layer, name, t.clone())
+            if len(layers) > 1:
+                assert len({getattr(l, "tlut" if hasattr(l, "tlut") else "lut").data_ptr() for l in layers}) == len(layers)
+            for a, b in zip(shared, qp.multi_gemv(layers, x)):
+                assert torch.equal(a, b), (qstr, n)
+
+
 def test_prezero_and_out_zeroed(qp, oracle):
     """A multi-job launch can pre-zero the output of a later split-K launch (gate|up zeroes down_proj's out)."""
     qstr = "tcomb_6_7_0.5_none_0.9"
