@@ -389,6 +389,25 @@ __global__ __launch_bounds__(256) void hadk_mix_kernel(HadParams p) {
     }
 }
 
+// Butterfly pass plan: how many index bits each pass handles in registers.  First pass 5 bits (the next pass then strides
+// by >= 32 floats: conflict-free LDS columns) — but only 3 for small transforms, which would otherwise keep just
+// hd / 32 threads busy (a 512-segment: 16 lanes doing all the SwiGLU and conversion work); the rest in even shares <= 5.
+void plan_passes(HadParams &p) {
+    const int first = p.hd <= 1024 ? 3 : p.hd <= 8192 ? 4 : 5;
+    int left = p.logP;
+    p.npass = 0;
+    if (left > 0) {
+        p.r[p.npass++] = left < first ? left : first;
+        left -= p.r[0];
+        const int more = (left + 4) / 5;
+        for (int i = 0; i < more; i++) {
+            const int take = (left + (more - i) - 1) / (more - i);
+            p.r[p.npass++] = take;
+            left -= take;
+        }
+    }
+}
+
 int launch_hadamard(const HadParams &p, hipStream_t stream) {
     if (p.K > 1 && p.K <= 32 && p.round_mid && p.logP >= 6 && p.hd > 4096) {
         // Two launches instead of one workgroup: (1) every 2^p-segment as its own K = 1 transform on its own compute
@@ -401,6 +420,7 @@ int launch_hadamard(const HadParams &p, hipStream_t stream) {
         a.post_scale = 1.0f;
         a.sv = nullptr;
         a.hadk = nullptr;
+        plan_passes(a);
         int rc = launch_hadamard(a, stream);
         if (rc) return rc;
         const int tiles = p.rows * (p.n / p.hd) * (a.hd >> 4);
@@ -464,18 +484,6 @@ extern "C" int qpal_hadamard(void *out_f16, const void *in, const void *su, cons
 #ifdef HAD_STAMPS
     p.dbg = g_had_dbg;
 #endif
-    // pass plan: 5 bits first (the next pass then strides by >= 32 floats: conflict-free LDS columns), the rest even
-    const int first = 5;
-    int left = logP;
-    if (left > 0) {
-        p.r[p.npass++] = left < first ? left : first;
-        left -= p.r[0];
-        const int more = (left + 4) / 5;
-        for (int i = 0; i < more; i++) {
-            const int take = (left + (more - i) - 1) / (more - i);
-            p.r[p.npass++] = take;
-            left -= take;
-        }
-    }
+    plan_passes(p);
     return launch_hadamard(p, static_cast<hipStream_t>(stream));
 }
