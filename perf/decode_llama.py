@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""End-to-end decode loop of a Llama-shaped model built from THIS package's modules.
+
+Counterpart of the reference's eval/measure_latency.py (HF model + StaticCache + CUDA graphs): every decoder layer is
+``IncoherentSdpaAttention`` + ``IncoherentMLP`` (qpalette_amd, dummy packed weights of the reference's shapes: quantizer
+string per linear or a published qdict with its merge_info), with a static KV cache, rotary embedding, RMSNorm, residuals,
+embedding and an fp16 lm_head.  One decode step is captured in a HIP graph and replayed.
+
+What is NOT this package's work and is left as plain torch ops (the reference gets them fused by torch.compile, which is
+Triton and therefore not used here): RMSNorm, rotary embedding, KV-cache update, SDPA, residual adds, argmax — a few
+hundred small launches per token.  The script reports the whole-step rate and, next to it, the rate of the quantized
+projections alone (same graph without the glue), so the two are not confused.
+
+    python perf/decode_llama.py [--quantizer tcomb_6_7_0.5_none_0.9 | --qdict figure1d] [--context 1024] [--tokens 64]
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+import types
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn as nn
+
+import qpalette_amd as qp
+
+LINEARS = ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj",
+           "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"]
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, n, eps=1e-5):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(n, dtype=torch.float16), requires_grad=False)
+        self.eps = eps
+
+    def forward(self, x):
+        v = x.float()
+        return (v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + self.eps)).to(x.dtype) * self.weight
+
+
+class StaticKV:
+    """Fixed-size key/value cache with the `update(k, v, layer_idx, kwargs)` method the attention module calls."""
+
+    def __init__(self, nlayers, kv_heads, head_dim, max_len, device):
+        shape = (1, kv_heads, max_len, head_dim)
+        self.k = [torch.zeros(shape, dtype=torch.float16, device=device) for _ in range(nlayers)]
+        self.v = [torch.zeros(shape, dtype=torch.float16, device=device) for _ in range(nlayers)]
+
+    def update(self, k, v, layer_idx, kwargs):
+        pos = kwargs["cache_position"]
+        self.k[layer_idx].index_copy_(2, pos, k)
+        self.v[layer_idx].index_copy_(2, pos, v)
+        return self.k[layer_idx], self.v[layer_idx]
+
+
+def _info(model_key, layer, key, qstr, device, gen):
+    li = qp.mem_op.get_layer_info(model_key)[key]
+    k, m = li["in_features"], li["out_features"]
+    return {"quant_info": qp.mem_op.get_quant_info(qstr), "in_features": k, "out_features": m, "dtype": torch.float16,
+            "bias": None,
+            "linear_info": qp.mem_op.dummy_linear_info(k, m, qstr, seed=layer * 16 + LINEARS.index(key), device=device,
+                                                       codebook_seed=777),
+            "SU": (torch.randint(0, 2, (k,), device=device, generator=gen) * 2 - 1).half(),
+            # small output scales keep the random model's residual stream finite in fp16 over 32 layers
+            "Wscale": (0.001 + 0.001 * torch.rand(m, device=device, generator=gen)).half()}
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, cfg, model_key, layer, qof, merges, device, gen):
+        super().__init__()
+        inf = {key: _info(model_key, layer, key, *qof(layer, key)[:1], device, gen) for key in LINEARS}
+        simt = {key: qof(layer, key)[1] for key in LINEARS}
+        q, k, v, o, g, u, d = LINEARS
+        self.self_attn = qp.IncoherentSdpaAttention.gen_layer_from_info(
+            cfg, layer, inf[q], inf[k], inf[v], inf[o], merge_qk="merge_qk" in merges, merge_qv="merge_qv" in merges,
+            merge_kv="merge_kv" in merges, merge_qkv="merge_qkv" in merges, use_simt_q=simt[q], use_simt_k=simt[k],
+            use_simt_v=simt[v], use_simt_o=simt[o]).to(device)
+        self.mlp = qp.IncoherentMLP.gen_layer_from_info(cfg, inf[u], inf[g], inf[d], merge_ug="merge_ug" in merges,
+                                                        use_simt_u=simt[u], use_simt_g=simt[g], use_simt_d=simt[d]).to(device)
+        self.input_layernorm = RMSNorm(cfg.hidden_size).to(device)
+        self.post_attention_layernorm = RMSNorm(cfg.hidden_size).to(device)
+
+    def forward(self, h, rope, mask, cache, pos, glue=True):
+        if not glue:  # the quantized projections alone: q|k|v, o, up|gate (+SwiGLU rotation), down
+            q, _, _ = self.self_attn.compute_qkv(h)
+            self.self_attn.compute_o(q)
+            self.mlp(h)
+            return h
+        a, _, _ = self.self_attn(self.input_layernorm(h), attention_mask=mask, past_key_value=cache, cache_position=pos,
+                                 position_embeddings=rope)
+        h = h + a
+        return h + self.mlp(self.post_attention_layernorm(h))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="3_8b", choices=sorted(qp.mem_op.LAYER_INFO))
+    ap.add_argument("--quantizer", default="tcomb_6_7_0.5_none_0.9")
+    ap.add_argument("--qdict", default=None, help="perf/qdicts/<name>.json (figure1c, figure1d) instead of --quantizer")
+    ap.add_argument("--layers", type=int, default=0)
+    ap.add_argument("--context", type=int, default=1024, help="static KV-cache length attended over")
+    ap.add_argument("--tokens", type=int, default=64)
+    ap.add_argument("--vocab", type=int, default=128256)
+    args = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("needs a GPU")
+    dev = torch.device("cuda", 0)
+    li = qp.mem_op.get_layer_info(args.model)
+    H, I = li["mlp.gate_proj"]["in_features"], li["mlp.gate_proj"]["out_features"]
+    kv_out = li["self_attn.k_proj"]["out_features"]
+    head_dim = 128
+    cfg = types.SimpleNamespace(hidden_size=H, intermediate_size=I, hidden_act="silu", num_attention_heads=H // head_dim,
+                                num_key_value_heads=kv_out // head_dim, head_dim=head_dim, attention_dropout=0.0)
+    nlayers = args.layers or li["nlayers"]
+    qdict, merge_info = None, None
+    if args.qdict:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "qdicts", args.qdict + ".json")) as f:
+            data = json.load(f)
+        qdict, merge_info = data["qdict"], data["merge_info"]
+
+    def qof(layer, key):
+        if qdict is None:
+            return args.quantizer, False
+        q, simt = qdict[f"{layer}_{key}"]
+        return q, simt == "1"
+
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    layers = nn.ModuleList([DecoderLayer(cfg, args.model, i, qof, set(merge_info[i]) if merge_info else set(), dev, gen)
+                            for i in range(nlayers)])
+    qp.share_codebooks([m for m in layers.modules() if hasattr(m, "tlut") or hasattr(m, "lut")])
+    embed = (torch.randn(args.vocab, H, device=dev, generator=gen) * 0.5).half()
+    lm_head = (torch.randn(args.vocab, H, device=dev, generator=gen) * 0.02).half()
+    norm = RMSNorm(H).to(dev)
+    cache = StaticKV(nlayers, cfg.num_key_value_heads, head_dim, args.context, dev)
+    inv_freq = 1.0 / (500000.0 ** (torch.arange(0, head_dim, 2, device=dev).float() / head_dim))
+    tok = torch.zeros(1, dtype=torch.long, device=dev)
+    pos = torch.zeros(1, dtype=torch.long, device=dev)
+    out_tok = torch.zeros(1, dtype=torch.long, device=dev)
+    ar = torch.arange(args.context, device=dev)
+
+    def step(glue=True):
+        h = embed[tok].view(1, 1, H)
+        rope = mask = None
+        if glue:
+            ang = pos.float()[:, None] * inv_freq[None, :]
+            emb = torch.cat((ang, ang), dim=-1)[None]                       # [1, 1, head_dim]
+            rope = (emb.cos().half(), emb.sin().half())
+            mask = torch.where(ar <= pos, 0.0, float("-inf")).half().view(1, 1, 1, -1)
+        for layer in layers:
+            h = layer(h, rope, mask, cache, pos, glue=glue)
+        if glue:
+            logits = norm(h).view(1, H) @ lm_head.T
+            out_tok.copy_(logits.argmax(-1))
+        return h
+
+    def timed(glue):
+        s = torch.cuda.Stream(dev)
+        with torch.cuda.stream(s):
+            step(glue)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                step(glue)
+            for i in range(4):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.tokens):
+                if glue:                       # the next step consumes the sampled token at the next position
+                    tok.copy_(out_tok)
+                    pos.fill_(min(args.context - 1, 8 + i))
+                g.replay()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / args.tokens
+
+    t_full = timed(True)
+    t_proj = timed(False)
+    finite = bool(torch.isfinite(step(True)).all())
+    packed = sum(t.numel() * t.element_size() for m in layers.modules() for name in ("trellis", "trellis1", "trellis2", "qweight")
+                 if (t := getattr(m, name, None)) is not None)
+    print(json.dumps({
+        "what": "decode step of a Llama-shaped model: incoherent quantized projections (this package) + torch glue",
+        "model": args.model, "layers": nlayers, "quantizer": args.qdict or args.quantizer, "context": args.context,
+        "tokens_per_s_whole_step": 1.0 / t_full, "ms_whole_step": t_full * 1e3,
+        "tokens_per_s_projections_only": 1.0 / t_proj, "ms_projections_only": t_proj * 1e3,
+        "glue_ms": (t_full - t_proj) * 1e3, "packed_weight_GB": packed / 1e9, "lm_head_GB": lm_head.numel() * 2 / 1e9,
+        "finite": finite}))
+
+
+if __name__ == "__main__":
+    main()

@@ -250,13 +250,12 @@ class IncoherentSdpaAttention(nn.Module):
             q, k = q * c + _rotate_half(q) * s, k * c + _rotate_half(k) * s
         if past_key_value is not None:
             k, v = past_key_value.update(k, v, self.layer_idx, {"sin": sin, "cos": cos, "cache_position": cache_position})
-        if self.num_key_value_groups > 1:
-            k = k.repeat_interleave(self.num_key_value_groups, dim=1)
-            v = v.repeat_interleave(self.num_key_value_groups, dim=1)
         mask = attention_mask[:, :, :, : k.shape[-2]] if attention_mask is not None else None
+        # grouped-query attention without materialising the repeated keys / values (the reference's repeat_kv)
         attn = F.scaled_dot_product_attention(q, k.to(q.dtype), v.to(q.dtype), attn_mask=mask,
                                               dropout_p=self.attention_dropout if self.training else 0.0,
-                                              is_causal=mask is None and q_len > 1)
+                                              is_causal=mask is None and q_len > 1,
+                                              enable_gqa=self.num_key_value_groups > 1)
         attn = attn.transpose(1, 2).contiguous().view(bsz, q_len, -1)
         return self.compute_o(attn), None, past_key_value
 
