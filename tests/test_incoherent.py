@@ -432,3 +432,29 @@ def test_fused_rotation_equals_separate_launch(qp, oracle, k, n=1):
     with pytest.raises(RuntimeError):
         qp.multi_gemv([qp.make_linear(_info(qp, 1024, 256, "tcq_4_0_1", 70)).cuda()],
                       torch.zeros(1, 1024, dtype=torch.float16, device="cuda"), x_rot=(None, 1.0))
+
+
+@gpu
+@pytest.mark.parametrize("n", [1, 20])
+def test_incoherent_mlp_70b_shapes_and_large_batch(qp, oracle, n):
+    """Llama-70B sizes (hidden 8192: rotation in a launch of its own; intermediate 28672 = 28 * 1024: two-launch K > 1 path)
+    and a batch beyond the fused GEMV (n = 20: decode-to-fp16 + GEMM path inside the wrapper)."""
+    cfg = _cfg(hidden=8192, inter=28672)
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    qstr = "tcq_3_0_1"
+    up, gate, down = _info(qp, H, I, qstr, 81), _info(qp, H, I, qstr, 82), _info(qp, I, H, qstr, 83)
+    mlp = qp.IncoherentMLP.gen_layer_from_info(cfg, up, gate, down, merge_ug=True).cuda()
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, H)).astype(np.float16)
+    y = mlp(torch.from_numpy(x).cuda())
+    scale = mlp.scale
+    hT = qp.hadamard.get_hadK(I)[0].numpy().T.astype(np.float64)
+    xr = oi.left_input(x, up["SU"].numpy(), None, scale)
+    au, mu = _lin(oracle, up, xr)
+    ag, mg = _lin(oracle, gate, xr)
+    act = oi.swiglu(oi.linear_post(au, up["Wscale"].numpy(), scale), oi.linear_post(ag, gate["Wscale"].numpy(), scale))
+    xd = oi.left_input(act, down["SU"].numpy(), hT, scale)
+    ad, md = _lin(oracle, down, xd)
+    want = oi.linear_post(ad, down["Wscale"].numpy(), scale)
+    assert y.dtype == torch.float16 and tuple(y.shape) == (n, H)
+    _close(y.cpu().numpy(), want, 2 * md * down["Wscale"].numpy().astype(np.float64) * scale + np.abs(want), "70B-shaped MLP")
