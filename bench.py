@@ -404,7 +404,7 @@ def main():
     value = tokens / wall
     nlinear = sum(len(grp) for groups in layers for grp in groups)
     multi = args.launch == "multi" and not tp
-    nlaunch = sum(len(qp.linear.launch_groups([m for m, _, _ in grp])) if multi else len(grp)
+    nlaunch = sum(len(qp.linear.launch_groups([m for m, _, _ in grp], mixed_kv=n <= 8 and not args.incoherent)) if multi else len(grp)
                   for groups in layers for grp in groups)  # GEMV kernel launches per token
     abytes = algorithmic_bytes(qp, layers, n) * (world if tp else 1)  # per token
     t_token = dev_s / args.steps

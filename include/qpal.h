@@ -70,6 +70,9 @@ typedef struct qpal_tcq_job {
                           that share x must share x_su / x_post */
     float x_post;      /* e.g. 1 / scale */
     const void *x_su;  /* fp16 [k] or NULL */
+    int kv;            /* 0: the call's KV1.  Otherwise this job's own KV (split NONE only): jobs of one S but different
+                          bit widths — q, k, v of a mixed-scheme model — then share ONE launch and one codebook image
+                          (KV 2..8 for S = 9, 8..10 for S = 10, 9..10 for S = 11; batch <= 8; no x_had) */
 } qpal_tcq_job;
 /* prezero/prezero_bytes (may be NULL/0): a buffer this launch also fills with zeros, for a LATER launch on the
  * same stream that accumulates into it with atomics (split-K of a few-rows x long-K layer such as down_proj).

@@ -19,7 +19,7 @@ class TcqJob(ctypes.Structure):
     """qpal_tcq_job (include/qpal.h)"""
     _fields_ = [("out", _P), ("c1", _P), ("c2", _P), ("x", _P), ("tlut", _P), ("m", _I), ("k", _I),
                 ("out_zeroed", _I), ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long),
-                ("x_had", _I), ("x_post", _F), ("x_su", _P)]
+                ("x_had", _I), ("x_post", _F), ("x_su", _P), ("kv", _I)]
 
 
 class LutJob(ctypes.Structure):

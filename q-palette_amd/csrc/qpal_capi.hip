@@ -232,9 +232,13 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
     TcMultiParams mp{};
     mp.njobs = njobs;
     int zeroed[kMaxJobs] = {0};
+    bool mixed = false;  // jobs with their own KV: the any-KV kernel of this S
     for (int j = 0; j < njobs; j++) {
         const qpal_tcq_job &jb = jobs[j];
-        int rc = tcq_check(jb.c1, jb.c2, jb.tlut, jb.m, jb.k, S, KV1, KV2, split);
+        const int kv = jb.kv ? jb.kv : KV1;
+        mixed = mixed || kv != KV1;
+        if (kv != KV1 && (split != QPAL_SPLIT_NONE || jb.x_had)) return QPAL_E_PARAM;
+        int rc = tcq_check(jb.c1, jb.c2, jb.tlut, jb.m, jb.k, S, kv, KV2, split);
         if (rc) return rc;
         if (!jb.out || !jb.x) return QPAL_E_NULL;
         if (!aligned(jb.x, 8) || !aligned(jb.out, 4) || (jb.k % 4)) return QPAL_E_ALIGN;
@@ -246,9 +250,17 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         else
             tcq_fill(mp.job[j], jb.out, ldo, jb.c1, jb.c2, jb.x, jb.tlut, jb.m, n, jb.k, jb.k / 2, jb.k / 2, jb.wscale,
                      jb.oscale);
+        mp.job[j].kv = kv;
         rc = set_rotation(mp.job[j], jb.x_had, jb.x_su, jb.x_post, n, jb.k);
         if (rc) return rc;
         zeroed[j] = jb.out_zeroed;
+    }
+    if (mixed) {
+        if (n > 8) return QPAL_E_SHAPE;
+        for (int j = 0; j < njobs; j++) {
+            const int kv = mp.job[j].kv;
+            if ((S == 9 && kv > 8) || (S == 10 && kv < 8) || (S == 11 && kv < 9)) return QPAL_E_PARAM;
+        }
     }
     mp.zero = static_cast<u32x4 *>(prezero);
     mp.zero_chunks = (int)(prezero_bytes / 16);
@@ -258,6 +270,7 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         int rc = zero_if_split(mp.job[j], jobs[j].m, s, jobs[j].out_zeroed);
         if (rc) return rc;
     }
+    if (mixed) return launch_tcq_gemv_any(mp, S, grid, s);
     return launch_tcq_gemv(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, n <= 8 ? 1 : 2, grid, s);
 }
 

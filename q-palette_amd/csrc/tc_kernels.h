@@ -53,6 +53,7 @@ struct TcParams {
     int x_lds;          // 1: stage x[n][k] in LDS (fits beside the codebook image)
     int base1, rem1;    // stream 1: st1 = nc1*base1 + rem1 (first rem1 chunks get one more step)
     int base2, rem2;    // stream 2: st2 = (nchunk-nc1)*base2 + rem2
+    int kv;                  // TcqAny kernels only: this job's KV (trellis dwords per lane)
     const uint16_t *x_su;    // gemv prologue rotation (x_rot != 0): fp16 [k] sign vector or null
     float x_pre, x_post;     //   staged x = fp16( fp16( H_k (x * su) * x_pre ) * x_post ), x_pre = k^-1/2
     int x_rot;               //   0: x is used as given; else k / 1024 (k in {2048, 4096}), needs x_lds
@@ -81,6 +82,7 @@ struct TcMultiParams {
 // for tile group G = ksub*2 + msub; state I in 0..7 (0..3 = lane A's j, 4..7 = lane B's j).
 template <int S, int KV>
 struct TcqCodec {
+    static constexpr int S_ = S;
     static constexpr int NW = KV;          // dwords per lane per supertile
     static constexpr int L4 = 4 * KV;      // stream bits per reference lane per tile
     static constexpr bool kNeedsNext = true;
@@ -368,6 +370,29 @@ __device__ __forceinline__ void gemv_run(uint32_t (&w)[Codec::NW], const uint32_
 template <int NBG>
 constexpr int scratch_bytes() { return NBG == 1 ? kScratchBytes : 16 * 32 * 4 * 8 * NBG; }
 
+// Mixed-precision launches: everything about a TCQ codec except the bit surgery depends on the codebook size S only (the
+// LDS image, its address mask, the hash), so single-stream layers of one S but DIFFERENT KV — q, k and v of a mixed-scheme
+// model each have their own bit width — can share one launch and one image.  TcqAny<S> stands for "KV is a per-job
+// runtime value": the kernel switches to the matching decode loop once per work item (workgroup-uniform).
+template <int S>
+struct TcqAny : TcqCodec<S, (S == 9 ? 8 : 10)> {
+    static constexpr bool kAny = true;
+    // KV range per S as the quantizer strings produce it: tlut_bits = 9 for KV <= 8, KV + 1 above (mem_op.py:274)
+    // (the reference's op table also lists (9, 9) and (9, 10); those stay with the per-KV kernels)
+    static constexpr int kMinKV = S == 9 ? 2 : S == 10 ? 8 : 9;
+    static constexpr int kMaxKV = S == 9 ? 8 : 10;
+};
+template <class C>
+constexpr bool is_any_v = requires { C::kAny; };
+
+// f(std::integral_constant<int, KV>) for the runtime kv (uniform across the workgroup)
+template <int S, class F>
+__device__ __forceinline__ void dispatch_kv(int kv, F &&f) {
+    static_for<TcqAny<S>::kMinKV, TcqAny<S>::kMaxKV + 1>([&](auto kc) {
+        if (kv == decltype(kc)::value) f(kc);
+    });
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused decode + GEMV / skinny GEMM, 1 <= n <= 8*NBG.  1024 threads (16 waves, 4 per SIMD), one workgroup per
 // CU (LDS-bound).  C2 == void: single stream.  Otherwise combt (columns [0,col2) from c1 via C1, the rest from
@@ -495,7 +520,9 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const uint16_t *ex, const
         int s0 = cc * base + (cc < rem ? cc : rem);
         int s1 = s0 + base + (cc < rem ? 1 : 0);
         if (!live) s0 = s1 = 0;
-        const StreamView sv1{p.c1 + (long)(live ? sr : 0) * p.nsc1 * 16 * C1::NW, p.nsc1, 0};
+        constexpr bool ANY = is_any_v<C1>;
+        const int nw1 = ANY ? p.kv : C1::NW;  // dwords per lane per supertile of stream 1
+        const StreamView sv1{p.c1 + (long)(live ? sr : 0) * p.nsc1 * 16 * nw1, p.nsc1, 0};
         const StreamView sv2{TWO ? p.c2 + (long)(live ? sr : 0) * p.nsc2 * 16 * CB::NW : p.c1, TWO ? p.nsc2 : p.nsc1,
                              p.col2};
         Acc<NBG> acc;
@@ -506,8 +533,15 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const uint16_t *ex, const
         });
 
         // first step's weights are in flight while x and the codebook image are (re)staged
-        if (on2) load_step_w<CB::NW>(sv2, s0, lane, w.b);
-        else load_step_w<C1::NW>(sv1, s0, lane, w.a);
+        if constexpr (ANY) {
+            dispatch_kv<C1::S_>(p.kv, [&](auto kc) {
+                constexpr int KVr = decltype(kc)::value;
+                load_step_w<KVr>(sv1, s0, lane, reinterpret_cast<uint32_t(&)[KVr]>(w.a));
+            });
+        } else {
+            if (on2) load_step_w<CB::NW>(sv2, s0, lane, w.b);
+            else load_step_w<C1::NW>(sv1, s0, lane, w.a);
+        }
         if constexpr (kEarly) {
             if (early && gitem == (int)blockIdx.x) {  // early staging, part 2: registers -> LDS
                 const int total = en * ek;
@@ -583,6 +617,15 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const uint16_t *ex, const
             __syncthreads();
         }
         QPAL_STAMP(3);
+        if constexpr (ANY) {
+            dispatch_kv<C1::S_>(p.kv, [&](auto kc) {
+                constexpr int KVr = decltype(kc)::value;
+                using CK = TcqCodec<C1::S_, KVr>;
+                auto &wk = reinterpret_cast<uint32_t(&)[KVr]>(w.a);
+                if (NBG == 1 && x_lds) gemv_run<CK, true, NBG>(wk, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else gemv_run<CK, false, NBG>(wk, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+            });
+        } else
         if constexpr (NBG == 1) {
             if (x_lds) {
                 if (on2) gemv_run<CB, true, 1>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);

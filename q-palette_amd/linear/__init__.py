@@ -60,11 +60,22 @@ def _codec_key(layer):
     return ("single", id(layer))
 
 
-def launch_groups(layers):
+def _launch_key(layer, mixed_kv):
+    """Key of the launch a layer can join.  mixed_kv: single-stream TCQ layers of one codebook size share a launch
+    whatever their KV (any-KV kernel: KV 2..8 at S = 9, 8..10 at S = 10, 9..10 at S = 11; fused batch <= 8)."""
+    key = _codec_key(layer)
+    if mixed_kv and key[0] == "tcq":
+        s, kv = layer.tlut_bits, layer.KV
+        if (s == 9 and kv <= 8) or (s == 10 and kv >= 8) or (s == 11 and kv >= 9):
+            return ("tcq", key[1], s, "any")
+    return key
+
+
+def launch_groups(layers, mixed_kv=False):
     """Partition `layers` (projections of one input) into multi-job launches: lists of indices, at most 8 each."""
     groups = {}
     for i, layer in enumerate(layers):
-        groups.setdefault(_codec_key(layer), []).append(i)
+        groups.setdefault(_launch_key(layer, mixed_kv), []).append(i)
     out = []
     for key, idxs in groups.items():
         if key[0] == "single":
@@ -101,7 +112,8 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
     if n > 16:
         return [l(x2) for l in layers]
     results = [None] * len(layers)
-    for idxs in launch_groups(layers):
+    mixed_kv = x_rot is None and n <= 8  # the any-KV kernel has no rotation / batch > 8 variants
+    for idxs in launch_groups(layers, mixed_kv):
         first = layers[idxs[0]]
         kind = _codec_key(first)[0]
         grp = [layers[i] for i in idxs]
@@ -109,7 +121,7 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
         ws = [wscales[i] for i in idxs] if wscales is not None else None
         extra = dict(outs=o, outs_zeroed=outs_zeroed, prezero=prezero, wscales=ws, oscale=oscale, x_rot=x_rot)
         if kind == "tcq":
-            ys = ops.tcq_gemv_multi([(l.trellis, None, l.tlut, l.out_features) for l in grp], x2, first.tlut_bits,
+            ys = ops.tcq_gemv_multi([(l.trellis, None, l.tlut, l.out_features, l.KV) for l in grp], x2, first.tlut_bits,
                                     first.KV, **extra)
             prezero = None
         elif kind == "tcombt":

@@ -278,7 +278,8 @@ def can_fuse_rotation(n, k):
 def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=False, prezero=None, wscales=None,
                    oscale=1.0, x_rot=None):
     """Several TCQ GEMVs of one codec and one input in ONE launch (C-ABI qpal_tcq_gemv_multi).
-    streams: list of (c1, c2_or_None, tlut, m); x: [n, k].  Returns the list of fp32 [n, m] outputs.
+    streams: list of (c1, c2_or_None, tlut, m) or (c1, None, tlut, m, KV): with per-stream KV, single-stream layers of one
+    codebook size but different bit widths share the launch.  x: [n, k].  Returns the list of fp32 [n, m] outputs.
     outs: write into these tensors (outs_zeroed: they are all zeros already); prezero: a tensor this launch
     also zeroes for a later split-K launch on the same stream.
     wscales / oscale: fused epilogue out = acc * wscales[j][row] * oscale (the incoherent wrappers' Wscale * scale).
@@ -289,12 +290,14 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
     had, xpost, xsu = _rot_args(x_rot, xh, k)
     jobs = (nat.TcqJob * len(streams))()
     results, keep = [], [xh]
-    for j, (c1, c2, tlut, m) in enumerate(streams):
+    for j, stream in enumerate(streams):
+        c1, c2, tlut, m = stream[:4]
+        kv = stream[4] if len(stream) > 4 else 0
         c1 = _dev(c1, "compressed1")
         tl = _dev(tlut, "codebook")
         _chk(tl.dtype == torch.float16 and tl.numel() == 2 << S, f"codebook must be fp16 with {2 << S} elements")
         if split == 0:
-            _tcq_stream_ok(c1, m, k, KV1, "compressed")
+            _tcq_stream_ok(c1, m, k, kv or KV1, "compressed")
         else:
             c2 = _dev(c2, "compressed2")
             _tcq_stream_ok(c1, m, k // 2, KV1, "compressed1")
@@ -302,7 +305,7 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
         out = _out_arg(outs, j, n, m, x.device)
         jobs[j] = nat.TcqJob(out.data_ptr(), c1.data_ptr(), c2.data_ptr() if c2 is not None else None,
                              xh.data_ptr(), tl.data_ptr(), m, k, 1 if (outs is not None and outs_zeroed) else 0,
-                             _wscale_arg(wscales, j, m), float(oscale), _ldo(out, n, m), had, xpost, xsu)
+                             _wscale_arg(wscales, j, m), float(oscale), _ldo(out, n, m), had, xpost, xsu, kv)
         results.append(out)
         keep += [c1, c2, tl]
     zp, zb = _prezero_args(prezero)

@@ -363,3 +363,34 @@ def test_fused_skinny_gemm_batch_9_to_16(qp, oracle, qstr, k, m):
         y = layer(x.cuda().float())
         assert y.dtype == torch.float32 and tuple(y.shape) == (n, m)
         _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle)
+
+
+def test_mixed_kv_projections_share_one_launch(qp, oracle):
+    """q, k, v of a mixed-scheme model have different bit widths: single-stream TCQ layers of one codebook size go out as
+    ONE launch (any-KV kernel, one codebook image) and agree with their own single launches and with the oracle."""
+    k = 4096
+    for kvs, ms in (((3, 6, 8), (4096, 1024, 1024)), ((2, 7), (14336, 14336)), ((8, 9, 10), (512, 256, 256)), ((9, 10), (1024, 32))):
+        layers = []
+        for i, (kv, m) in enumerate(zip(kvs, ms)):
+            qstr = f"tcq_{kv}_none_0.9"
+            info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=100 + i, codebook_seed=3 if kv <= 8 else 30 + kv)
+            layers.append((qp.make_linear_from_info(qstr, info).cuda(), qstr, info))
+        mods = [l for l, _, _ in layers]
+        qp.share_codebooks(mods)
+        groups = qp.linear.launch_groups(mods, mixed_kv=True)
+        sizes = sorted(len(g) for g in groups)
+        # S = 9 (KV <= 8), 10 (KV 9) and 11 (KV 10) are different codebooks: (8, 9, 10) stays three launches
+        assert sizes == ([len(kvs)] if max(kvs) <= 8 else [1] * len(kvs)), (kvs, sizes)
+        for n in (1, 3, 8):
+            x = torch.randn(n, k, generator=torch.Generator().manual_seed(n)).cuda()
+            ys = qp.multi_gemv(mods, x)
+            for (mod, qstr, info), y in zip(layers, ys):
+                ref = mod._gemv(x, n)   # (its own launch may cut K differently: summation order, not arithmetic)
+                assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max())), (kvs, qstr, n)
+            if n == 3:
+                for (mod, qstr, info), y, m in zip(layers, ys, ms):
+                    _check_gemv(y.cpu().numpy(), _oracle_weight(oracle, qstr, info, m, k), x.half().cpu().numpy(), oracle)
+        # batch 12 falls back to one launch per codec (the any-KV kernel has no two-batch-group variant)
+        x = torch.randn(12, k, generator=torch.Generator().manual_seed(12)).cuda()
+        for (mod, _, _), y in zip(layers, qp.multi_gemv(mods, x)):
+            assert torch.allclose(y, mod._gemv(x, 12), rtol=1e-4, atol=1e-4 * float(y.abs().max()))
