@@ -13,7 +13,8 @@
 //            stage 2 if the k slots of a 32-row chunk are numbered rho = 32 kc + 16 (e >> 2) + 4 q + (e & 3):
 //            no data movement between the stages, the permutation only changes which signs A holds.
 //            D1 goes in as an fp16 hi + lo pair (two MFMAs): fp32-grade, the result differs from an fp32 butterfly
-//            network only in the last fp32 bits.
+//            network only in the last fp32 bits.  (D1 / 8 must fit fp16: |x| < 8188 — activations behind an RMSNorm are
+//            orders of magnitude below; the LDS butterfly kernel has no such bound.)
 //
 // v_mfma_f32_16x16x32_f16 operand layouts: A lane (q = lane >> 4, r = lane & 15) = A[row r][k = 8q + e];
 // B lane (q, j) = B[k = 8q + e][col j]; D lane (q, j) = D[row 4q + i][col j], i = 0..3.
