@@ -443,8 +443,9 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const uint16_t *ex, const
     int cur_j = 0;
     // early staging, part 1: request x and the codebook entries from the preloaded arguments (held in registers until
     // the first weight loads have been issued)
-    constexpr bool kEarly = NBG == 1 && !ROT;
     constexpr int NV = (C1::CHUNKS + 1023) / 1024;
+    // (the 128 KiB images of the wide VQ/SQ codebooks would hold 8 entries per thread: spills, measured 20-30 % slower)
+    constexpr bool kEarly = NBG == 1 && !ROT && NV <= 4;
     [[maybe_unused]] u32x4 exr[2];
     [[maybe_unused]] uint32_t etv[NV];
     const bool early = kEarly && eon != 0;
