@@ -38,8 +38,7 @@ class RMSNorm(nn.Module):
         self.eps = eps
 
     def forward(self, x):
-        v = x.float()
-        return (v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + self.eps)).to(x.dtype) * self.weight
+        return torch.nn.functional.rms_norm(x, (x.shape[-1],), self.weight, self.eps)  # one launch
 
 
 class StaticKV:
