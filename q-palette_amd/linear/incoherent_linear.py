@@ -43,33 +43,43 @@ def _had_buffer(n):
     return (hadK.T.contiguous().to(torch.float16) if hadK is not None else None), K
 
 
-def _scaled_linears(layers, x16, wscales, scale, out=None):
-    """[layer(x) * wscale * scale for layer in layers] as column blocks of ONE fp32 [n, sum m] buffer."""
+def _scaled_linears(layers, x16, wscales, scale, out=None, out_zeroed=False, prezero=None, x_rot=None):
+    """[layer(x) * wscale * scale for layer in layers] as column blocks of ONE fp32 [n, sum m] buffer.
+    out / out_zeroed: destination (already all zeros: a split-K layer then needs no memset of its own);
+    prezero: a buffer the launch also zeroes for the NEXT projection of the block (o_proj after q|k|v, down_proj after
+    up|gate) — the memset-free chain of multi_gemv."""
     n = x16.shape[0]
     widths = [l.out_features for l in layers]
     if out is None:
         out = torch.empty((n, sum(widths)), dtype=torch.float32, device=x16.device)
+        out_zeroed = False
     if all(isinstance(l, PackedLinearBase) for l in layers) and n <= 16:
         outs = list(out.split(widths, dim=1))
-        multi_gemv(layers, x16, outs=outs, wscales=wscales, oscale=scale)
+        multi_gemv(layers, x16, outs=outs, outs_zeroed=out_zeroed, prezero=prezero, wscales=wscales, oscale=scale, x_rot=x_rot)
     else:  # unquantized ("default") layers or large batches: plain torch
+        assert x_rot is None
         for l, w, o in zip(layers, wscales, out.split(widths, dim=1)):
             o.copy_(l(x16).float() * w.float() * scale)
+        if prezero is not None:
+            prezero.zero_()
     return out
 
 
-def _rotated_linears(layers, x16, su, hadK, K, wscales, scale):
-    """_scaled_linears(layers, rotate(x16 * su) / scale): where the sizes allow (k = 2048 / 4096, small batch,
+def _rotated_linears(layers, x16, su, hadK, K, wscales, scale, **kw):
+    """_scaled_linears(layers, rotate(x16 * su) / scale): where the sizes allow (k = 2048 / 4096, batch 1,
     tensor-core-order layers) the rotation runs inside the GEMV launches and costs no launch of its own."""
     n = x16.shape[0]
     if K == 1 and n <= 16 and all(isinstance(l, PackedLinearBase) for l in layers) and rotation_fusable(layers, n):
-        widths = [l.out_features for l in layers]
-        out = torch.empty((n, sum(widths)), dtype=torch.float32, device=x16.device)
-        multi_gemv(layers, x16, outs=list(out.split(widths, dim=1)), wscales=wscales, oscale=scale,
-                   x_rot=(su, 1.0 / scale))
-        return out
+        return _scaled_linears(layers, x16, wscales, scale, x_rot=(su, 1.0 / scale), **kw)
     xr = had.rotate(x16, hadK=hadK, K=K, su=su, post_scale=1.0 / scale)
-    return _scaled_linears(layers, xr, wscales, scale)
+    return _scaled_linears(layers, xr, wscales, scale, **kw)
+
+
+def _next_out(x16, layer):
+    """Output buffer of the next projection of a block, to be zeroed by the launch before it (None if not useful)."""
+    if isinstance(layer, PackedLinearBase) and x16.shape[0] <= 16:
+        return torch.empty((x16.shape[0], layer.out_features), dtype=torch.float32, device=x16.device)
+    return None
 
 
 class IncoherentMLP(nn.Module):
@@ -94,16 +104,16 @@ class IncoherentMLP(nn.Module):
         self.merge_ug = merge_ug
 
     # ---- fused pipeline (what forward runs)
-    def _ug_raw(self, x16):
+    def _ug_raw(self, x16, prezero=None):
         """fp32 [n, 2I] = up | gate, already `* Wscale_ug * scale`."""
         inter = self.intermediate_size
         rot = (self.SU_ug, self.had_left_ug_T, self.hidden_K)
         if self.merge_ug:
-            return _rotated_linears([self.ug_proj], x16, *rot, [self.Wscale_ug], self.scale)
+            return _rotated_linears([self.ug_proj], x16, *rot, [self.Wscale_ug], self.scale, prezero=prezero)
         return _rotated_linears([self.up_proj, self.gate_proj], x16, *rot,
-                                [self.Wscale_ug[:inter], self.Wscale_ug[inter:]], self.scale)
+                                [self.Wscale_ug[:inter], self.Wscale_ug[inter:]], self.scale, prezero=prezero)
 
-    def _dp_from_raw(self, ug):
+    def _dp_from_raw(self, ug, out=None):
         if self.hidden_act in ("silu", "swish"):
             xr = had.rotate(ug, hadK=self.had_left_dp_T, K=self.inter_K, su=self.SU_dp, post_scale=1.0 / self.scale,
                             in_mode=had.IN_SWIGLU_F32)
@@ -111,12 +121,13 @@ class IncoherentMLP(nn.Module):
             up, gate = ug.half().split(self.intermediate_size, dim=-1)
             xr = had.rotate((self.act_fn(gate) * up).contiguous(), hadK=self.had_left_dp_T, K=self.inter_K, su=self.SU_dp,
                             post_scale=1.0 / self.scale)
-        return _scaled_linears([self.down_proj], xr, [self.Wscale_dp], self.scale)
+        return _scaled_linears([self.down_proj], xr, [self.Wscale_dp], self.scale, out=out, out_zeroed=out is not None)
 
     def forward(self, input):
         n = len(self.SU_ug)
         x = input.reshape(-1, n).half()
-        y = self._dp_from_raw(self._ug_raw(x))
+        dp_out = _next_out(x, self.down_proj)  # zeroed by the up|gate launch: down_proj's split-K needs no memset
+        y = self._dp_from_raw(self._ug_raw(x, prezero=dp_out), out=dp_out)
         return y.view(*input.shape[:-1], n).to(input.dtype)
 
     # ---- the reference's two-step interface (l.325-337), same semantics
@@ -224,7 +235,10 @@ class IncoherentSdpaAttention(nn.Module):
         n = len(self.SU_qkv)
         x = input.reshape(-1, n).half()
         layers, wscales, blocks = self._qkv_layout()
-        out = _rotated_linears(layers, x, self.SU_qkv, self.had_left_qkv_T, self.hidden_K, wscales, self.scale).half()
+        # the q|k|v launch zeroes o_proj's output for the compute_o that follows (split-K without a memset)
+        self._o_out = _next_out(x, self.o_proj)
+        out = _rotated_linears(layers, x, self.SU_qkv, self.had_left_qkv_T, self.hidden_K, wscales, self.scale,
+                               prezero=self._o_out).half()
         parts = dict(zip([b[0] for b in blocks], out.split([b[1] for b in blocks], dim=-1)))
         lead = input.shape[:-1]
         return (parts["q"].reshape(*lead, n), parts["k"].reshape(*lead, self.kv_out),
@@ -233,7 +247,11 @@ class IncoherentSdpaAttention(nn.Module):
     def compute_o(self, input):
         n = len(self.SU_o)
         x = input.reshape(-1, n).half()
-        out = _rotated_linears([self.o_proj], x, self.SU_o, self.had_left_o_T, self.hidden_K, [self.Wscale_o], self.scale)
+        pre, self._o_out = getattr(self, "_o_out", None), None
+        if pre is not None and pre.shape[0] != x.shape[0]:
+            pre = None
+        out = _rotated_linears([self.o_proj], x, self.SU_o, self.had_left_o_T, self.hidden_K, [self.Wscale_o], self.scale,
+                               out=pre, out_zeroed=pre is not None)
         return out.half().view(*input.shape[:-1], n)
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
