@@ -458,3 +458,39 @@ def test_incoherent_mlp_70b_shapes_and_large_batch(qp, oracle, n):
     want = oi.linear_post(ad, down["Wscale"].numpy(), scale)
     assert y.dtype == torch.float16 and tuple(y.shape) == (n, H)
     _close(y.cpu().numpy(), want, 2 * md * down["Wscale"].numpy().astype(np.float64) * scale + np.abs(want), "70B-shaped MLP")
+
+
+@gpu
+def test_incoherent_modules_under_hip_graph(qp):
+    """A decoder block's projections captured once and replayed (how a decode loop runs them): same bits as eager,
+    including the pre-zero chain between the launches and the two-launch K > 1 rotation."""
+    cfg = _cfg(hidden=2048, inter=3584)
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    qstr = "tcomb_6_7_0.5_0_1"
+    mlp = qp.IncoherentMLP.gen_layer_from_info(cfg, _info(qp, H, I, qstr, 91), _info(qp, H, I, qstr, 92),
+                                               _info(qp, I, H, qstr, 93)).cuda()
+    attn = qp.IncoherentSdpaAttention.gen_layer_from_info(cfg, 0, _info(qp, H, H, qstr, 94), _info(qp, H, 512, qstr, 95),
+                                                          _info(qp, H, 512, qstr, 96), _info(qp, H, H, qstr, 97)).cuda()
+    x = torch.randn(1, 1, H, device="cuda").half()
+
+    def block(inp):
+        a, _, _ = attn(inp)
+        return mlp(inp + a)
+
+    eager = block(x).clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        block(x)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            y = block(x)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, eager)
+        x.copy_(torch.randn(1, 1, H, device="cuda").half())   # new input, same graph
+        g.replay()
+        torch.cuda.synchronize()
+        replayed = y.clone()
+    assert torch.equal(replayed, block(x))
