@@ -66,6 +66,9 @@ def parse_args():
                     help="run every projection group inside the reference's incoherence wrapper: sign flip + Hadamard + "
                          "1/scale before (one qpal_hadamard launch, SwiGLU fused for down_proj), Wscale*scale fused into "
                          "the GEMV epilogue (SURVEY §8 f-1)")
+    ap.add_argument("--packing", default="qdict", choices=["qdict", "mi355x"],
+                    help="qdict workloads: tensor-core-order vs SIMT packing of the VQ/SQ layers as published (chosen from the "
+                         "reference's RTX 4090 latency table) or re-chosen from this GPU's table (perf/latency/)")
     ap.add_argument("--no-incoherent-extra", action="store_true",
                     help="skip the second figure (token with the incoherence wrapper) of the default run")
     ap.add_argument("--no-fuse-rotation", action="store_true",
@@ -78,7 +81,26 @@ def parse_args():
     return ap.parse_args()
 
 
-def build_model(qp, torch, model_key, qstr, nlayers, device, shard=None, distinct_codebooks=False):
+_KIND = {"self_attn.q_proj": "q", "self_attn.k_proj": "k", "self_attn.v_proj": "v", "self_attn.o_proj": "o",
+         "mlp.gate_proj": "g", "mlp.up_proj": "u", "mlp.down_proj": "d"}
+
+
+def _mi355x_prefers_simt(keys, qstr):
+    """Packing choice from THIS GPU's latency table (perf/latency/3_8b_latency_coeffs_mi355x.json, the MI355X counterpart of
+    the table the reference's solver reads): the published qdicts carry the choice made from the RTX 4090 table."""
+    global _LAT
+    try:
+        _LAT
+    except NameError:
+        with open(os.path.join(ROOT, "perf", "latency", "3_8b_latency_coeffs_mi355x.json")) as f:
+            _LAT = json.load(f)
+    kind = "".join(_KIND[k] for k in keys)
+    kind = {"gu": "ug", "ug": "ug"}.get(kind, kind)
+    tc, simt = _LAT.get(f"{kind}_{qstr}_False"), _LAT.get(f"{kind}_{qstr}_True")
+    return tc is not None and simt is not None and simt < tc
+
+
+def build_model(qp, torch, model_key, qstr, nlayers, device, shard=None, distinct_codebooks=False, packing="qdict"):
     """-> list over layers of 4 groups [attention inputs (q,k,v), o, mlp inputs (gate,up), down]; a group is a
     list of (module, in_features, linear_info-or-None) that share one input vector.  Every layer has
     distinct packed buffers.  qstr "qdict:<name>": quantizer per linear (+ fused layers) from perf/qdicts."""
@@ -106,7 +128,8 @@ def build_model(qp, torch, model_key, qstr, nlayers, device, shard=None, distinc
         info = infos[0]
         for other in infos[1:]:
             info = cls.merge_infos(info, other)
-        if simt0 == "1" and "ldlq" in q0:
+        use_simt = simt0 == "1" if packing == "qdict" else _mi355x_prefers_simt(keys, q0)
+        if use_simt and "ldlq" in q0:
             mod = qp.VQLinearPackSIMT.gen_layer_from_info(info, device=device)
         else:
             mod = cls.gen_layer_from_info(info).to(device)
@@ -217,7 +240,7 @@ def main():
     tp = args.parallel == "tp" and world > 1
     torch.manual_seed(1234)
     layers = build_model(qp, torch, model_key, qstr, nlayers, device, shard=(rank, world) if tp else None,
-                         distinct_codebooks=args.distinct_codebooks)
+                         distinct_codebooks=args.distinct_codebooks, packing=args.packing)
     n = args.batch
     xs = {}
     for groups in layers:
