@@ -139,7 +139,7 @@ int qpal_tc_to_simt(void *dst_simt, const void *src_tc, int m, int k, int bits, 
  *   round_mid 1: fp16 between the butterflies and the hadK product (matmul_hadU_cuda's fp16 pipeline);
  *             0: fp32-grade throughout (matmul_hadU_head_cuda's float path)
  * hd * 4 bytes (+ 1/32 padding) must fit the 160 KiB LDS (hd <= 39 k); K > 1 needs hd / K >= 16; `in` and `su`
- * 16-byte aligned.                          */
+ * 16-byte aligned; `out` must not be `in`.                          */
 #define QPAL_IN_F16 0
 #define QPAL_IN_F32 1
 #define QPAL_IN_SWIGLU_F32 2

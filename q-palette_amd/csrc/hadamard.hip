@@ -463,6 +463,7 @@ extern "C" void qpal_debug_had_stamps(void *buf) { g_had_dbg = static_cast<unsig
 extern "C" int qpal_hadamard(void *out_f16, const void *in, const void *su, const void *sv, const void *hadk, int rows,
                              int n, int hd, int K, int in_mode, int round_mid, float post_scale, void *stream) {
     if (!out_f16 || !in) return QPAL_E_NULL;
+    if (out_f16 == in) return QPAL_E_PARAM;  // not in place: the waves of a block read all of it while others already write
     if (K < 1 || K > 256 || (K > 1 && !hadk)) return K > 1 && !hadk ? QPAL_E_NULL : QPAL_E_PARAM;
     if (in_mode < QPAL_IN_F16 || in_mode > QPAL_IN_SWIGLU_F32) return QPAL_E_PARAM;
     if (rows < 1 || rows > 65535 || n < 1 || hd < 1 || n % hd || hd % K) return QPAL_E_SHAPE;

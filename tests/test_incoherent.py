@@ -76,12 +76,15 @@ def test_capi_hadamard_argument_checks():
     E_SHAPE, E_PARAM, E_NULL = -1, -2, -3
     call = lib.qpal_hadamard
     assert call(None, p, None, None, None, 1, 64, 64, 1, 0, 1, 1.0, None) == E_NULL
-    assert call(p, p, None, None, None, 1, 64, 64, 12, 0, 1, 1.0, None) == E_NULL      # K > 1 needs hadk
-    assert call(p, p, None, None, None, 1, 96, 96, 1, 0, 1, 1.0, None) == E_SHAPE      # 96 is not a power of two
-    assert call(p, p, None, None, p, 1, 96, 96, 12, 0, 1, 1.0, None) == E_SHAPE        # P = 8 < 16
-    assert call(p, p, None, None, None, 1, 64, 48, 1, 0, 1, 1.0, None) == E_SHAPE      # hd does not divide n
-    assert call(p, p, None, None, None, 1, 64, 64, 1, 7, 1, 1.0, None) == E_PARAM
-    assert call(p, p, None, None, None, 1, 65536, 65536, 1, 0, 1, 1.0, None) == E_SHAPE  # does not fit the LDS
+    buf2 = (ctypes.c_uint16 * 64)()
+    p2 = ctypes.cast(buf2, ctypes.c_void_p)
+    assert call(p, p, None, None, None, 1, 64, 64, 1, 0, 1, 1.0, None) == E_PARAM      # in place is refused
+    assert call(p, p2, None, None, None, 1, 64, 64, 12, 0, 1, 1.0, None) == E_NULL     # K > 1 needs hadk
+    assert call(p, p2, None, None, None, 1, 96, 96, 1, 0, 1, 1.0, None) == E_SHAPE      # 96 is not a power of two
+    assert call(p, p2, None, None, p, 1, 96, 96, 12, 0, 1, 1.0, None) == E_SHAPE        # P = 8 < 16
+    assert call(p, p2, None, None, None, 1, 64, 48, 1, 0, 1, 1.0, None) == E_SHAPE      # hd does not divide n
+    assert call(p, p2, None, None, None, 1, 64, 64, 1, 7, 1, 1.0, None) == E_PARAM
+    assert call(p, p2, None, None, None, 1, 65536, 65536, 1, 0, 1, 1.0, None) == E_SHAPE  # does not fit the LDS
 
 
 def _cfg(hidden=1024, inter=3584, heads=8, kv_heads=2):
