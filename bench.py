@@ -54,9 +54,12 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--streams", type=int, default=1,
                     help="1: every GEMV on one stream; 3: q|k|v and gate|up fork onto side streams inside the graph")
-    ap.add_argument("--launch", default="multi", choices=["single", "multi"],
+    ap.add_argument("--launch", default="chain", choices=["single", "multi", "chain"],
                     help="single: one launch per linear (7/layer); multi: q|k|v and gate|up (projections of one input) "
-                         "go out as one multi-job launch each (4 launches/layer, same arithmetic, same buffers)")
+                         "go out as one multi-job launch each (4 launches/layer, same arithmetic, same buffers); chain "
+                         "(default): the same multi-job GEMVs as PHASES of one persistent launch per run of equal codecs — "
+                         "stream order between phases kept by an in-kernel arrival counter (csrc/tc_chain.h); phases no "
+                         "chain can take (SIMT packing, mixed codecs in one phase, batch > 8) run as multi-job launches")
     ap.add_argument("--distinct-codebooks", action="store_true",
                     help="give every linear its own random codebook (default: one codebook per model, as in real "
                          "Q-Palette checkpoints where every layer stores a copy of the same k-means codebook)")
@@ -256,7 +259,7 @@ def main():
     inc = []
 
     def build_incoherent_state():
-        assert args.launch == "multi" and gather is None, "--incoherent runs on the multi-job launch path"
+        assert args.launch in ("multi", "chain") and gather is None, "--incoherent runs on the multi-job launch path"
         gen = torch.Generator(device=device).manual_seed(4321)
         for groups in layers:
             per = []
@@ -315,9 +318,37 @@ def main():
                     outs += qp.multi_gemv(mods, xr, **kw)
         return outs
 
+    parts = None  # --launch chain: GemvChain objects (one launch each) and left-over Phases (multi-job launches)
+    if args.launch == "chain" and gather is None and not args.incoherent:
+        Phase = qp.chain.Phase
+        plan = []
+        for groups in layers:
+            pre = {}
+            for gi, grp in enumerate(groups):
+                ph = Phase(layers=[m for m, _, _ in grp], x=xs[grp[0][1]])
+                if gi in (0, 2) and not args.no_prezero and len(groups[gi + 1]) == 1:
+                    pre[gi + 1] = torch.empty((n, groups[gi + 1][0][0].out_features), dtype=torch.float32, device=device)
+                    ph.prezero = pre[gi + 1]
+                elif gi in pre:
+                    ph.outs, ph.outs_zeroed = [pre[gi]], True
+                plan.append(ph)
+        parts = qp.chain.build_chains(plan, n, device)
+
+    def token_chain():
+        outs = []
+        for part in parts:
+            if isinstance(part, qp.chain.GemvChain):
+                part.launch()
+                outs += [y for ph in part.phases for y in ph.results]
+            else:
+                outs += qp.multi_gemv(part.layers, part.x, outs=part.outs, outs_zeroed=part.outs_zeroed, prezero=part.prezero)
+        return outs
+
     def token():
         if args.incoherent:
             return token_incoherent()
+        if parts is not None:
+            return token_chain()
         outs = []
         for groups in layers:
             pre = {}  # group index -> output buffer zeroed by an earlier launch of this block
@@ -394,7 +425,7 @@ def main():
     # Second figure (N = 1 only, after the timed region of the headline): the same token with every projection group
     # inside the reference's incoherence wrapper (rotation + scales), i.e. what an IncoherentMLP / attention forward costs.
     extra = None
-    if world == 1 and not args.incoherent and not args.no_incoherent_extra and args.launch == "multi" and graph is not None:
+    if world == 1 and not args.incoherent and not args.no_incoherent_extra and args.launch in ("multi", "chain") and graph is not None:
         try:
             build_incoherent_state()
             with torch.cuda.stream(main_stream):
@@ -426,9 +457,15 @@ def main():
     tokens = args.steps * n * (1 if tp else world)
     value = tokens / wall
     nlinear = sum(len(grp) for groups in layers for grp in groups)
-    multi = args.launch == "multi" and not tp
-    nlaunch = sum(len(qp.linear.launch_groups([m for m, _, _ in grp], mixed_kv=n <= 8 and not args.incoherent)) if multi else len(grp)
-                  for groups in layers for grp in groups)  # GEMV kernel launches per token
+    multi = args.launch in ("multi", "chain") and not tp
+    mixed_kv = n <= 8 and not args.incoherent
+    nphase = sum(len(qp.linear.launch_groups([m for m, _, _ in grp], mixed_kv=mixed_kv)) if multi else len(grp)
+                 for groups in layers for grp in groups)  # dependent multi-job GEMVs per token
+    nlaunch = nphase  # GEMV kernel launches per token
+    if parts is not None:
+        nlaunch = sum(1 if isinstance(p_, qp.chain.GemvChain) else len(qp.linear.launch_groups(p_.layers, mixed_kv=mixed_kv))
+                      for p_ in parts)
+        assert qp.chain.chain_error(device) == 0, "a chain launch gave up waiting for a dependency"
     abytes = algorithmic_bytes(qp, layers, n) * (world if tp else 1)  # per token
     t_token = dev_s / args.steps
     achieved = abytes / (world if tp else 1) / t_token / 1e9  # per GPU
@@ -443,14 +480,17 @@ def main():
         "config": {"workload": f"{args.workload}: {nlayers} layers, {nlinear} quantized linears ({qstr}), batch {n}, "
                                f"{'HIP-graph replay' if graph is not None else 'eager'}, {args.streams} stream(s)",
                    "parallelism": (f"tp{world} row-sharded + all-gather" if tp else f"dp{world} replicas"),
-                   "linears_per_token": nlinear, "launches_per_token": nlaunch, "launch_mode": args.launch,
+                   "linears_per_token": nlinear, "launches_per_token": nlaunch, "phases_per_token": nphase,
+                   "launch_mode": args.launch,
                    "incoherent": bool(args.incoherent),
                    "rotation_launches_per_token": (nlayers + nrot[0]) if args.incoherent else 0},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
-                     "kernel": "qpal::tc_gemv_kernel (every GEMV launch of a token)",
+                     "kernel": ("qpal::tc_chain_kernel (persistent: every GEMV phase of a token)" if parts is not None
+                                else "qpal::tc_gemv_kernel (every GEMV launch of a token)"),
                      "algorithmic_bytes_per_launch": abytes / (world if tp else 1) / nlaunch,
-                     "avg_launch_us": t_token / nlaunch * 1e6},
+                     "avg_launch_us": t_token / nlaunch * 1e6,
+                     "avg_phase_us": t_token / nphase * 1e6},
     }
     if extra is not None:
         out["with_incoherence_wrapper"] = extra

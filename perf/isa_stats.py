@@ -29,4 +29,4 @@ rest = [l for n, l in enumerate(body) if n not in inside]
 c = hist(rest)
 print('outside loops: VALU', sum(v for kk, v in c.items() if kk.startswith('v_')), 'SALU', sum(v for kk, v in c.items() if kk.startswith('s_')))
 print('   ', c.most_common(25))
-k2 = s.index('.amdhsa_next_free_vgpr', j); print(s[k2:k2+32].strip())
+

@@ -19,13 +19,24 @@ class TcqJob(ctypes.Structure):
     """qpal_tcq_job (include/qpal.h)"""
     _fields_ = [("out", _P), ("c1", _P), ("c2", _P), ("x", _P), ("tlut", _P), ("m", _I), ("k", _I),
                 ("out_zeroed", _I), ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long),
-                ("x_had", _I), ("x_post", _F), ("x_su", _P), ("kv", _I)]
+                ("x_had", _I), ("x_post", _F), ("x_su", _P), ("kv", _I),
+                ("x_f32", _P), ("x_f32_scale", _F), ("x_fresh", _I), ("publish", _I)]
 
 
 class LutJob(ctypes.Structure):
     """qpal_lut_job (include/qpal.h)"""
     _fields_ = [("out", _P), ("qweight", _P), ("x", _P), ("lut", _P), ("m", _I), ("k", _I), ("out_zeroed", _I),
-                ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long), ("x_had", _I), ("x_post", _F), ("x_su", _P)]
+                ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long), ("x_had", _I), ("x_post", _F), ("x_su", _P),
+                ("x_f32", _P), ("x_f32_scale", _F), ("x_fresh", _I), ("publish", _I)]
+
+
+class ChainPhase(ctypes.Structure):
+    """qpal_chain_phase (include/qpal.h)"""
+    _fields_ = [("tcq_jobs", ctypes.POINTER(TcqJob)), ("lut_jobs", ctypes.POINTER(LutJob)), ("njobs", _I),
+                ("prezero", _P), ("prezero_bytes", ctypes.c_long)]
+
+
+CHAIN_WS_BYTES = 2048
 
 
 _SIGNATURES = {
@@ -44,6 +55,9 @@ _SIGNATURES = {
     "qpal_pack_lut_tc": [_P, _P, _I, _I, _I, _I],
     "qpal_pack_lut_simt": [_P, _P, _I, _I, _I, _I],
     "qpal_hadamard": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "qpal_tcq_chain_build": [_P, ctypes.c_long, ctypes.POINTER(ChainPhase), _I, _I, _I, _I, _I, _I, _I],
+    "qpal_lut_chain_build": [_P, ctypes.c_long, ctypes.POINTER(ChainPhase), _I, _I, _I, _I, _I],
+    "qpal_chain_launch": [_P, _P, _P, _P, _P],
 }
 
 
@@ -73,6 +87,8 @@ def lib():
         l.qpal_error_string.argtypes = [_I]
         l.qpal_error_string.restype = ctypes.c_char_p
         l.qpal_version.restype = _I
+        l.qpal_chain_blob_bytes.argtypes = [_I]
+        l.qpal_chain_blob_bytes.restype = ctypes.c_long
         _lib = l
     return _lib
 
@@ -84,4 +100,4 @@ def check(rc, what):
 
 
 def exported_symbols():
-    return list(_SIGNATURES) + ["qpal_error_string", "qpal_version"]
+    return list(_SIGNATURES) + ["qpal_error_string", "qpal_version", "qpal_chain_blob_bytes"]

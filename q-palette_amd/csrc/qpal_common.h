@@ -27,25 +27,37 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
+// Pointers that a kernel reads from MEMORY (the phase table of a chain launch) are generic to the compiler: their loads
+// become flat_load, which counts in BOTH vmcnt and lgkmcnt and completes out of order — every LDS wait of the decode then
+// waits for the weight stream as well (measured: 7x slower).  Everything the kernels touch through such pointers lives in
+// global memory: say so.
+template <class T>
+using gptr = __attribute__((address_space(1))) T *;
+template <class T>
+__device__ __forceinline__ gptr<T> as_global(T *p) {
+    return (gptr<T>)p;
+}
+
 // Streamed-once weights: KV (or `bits`) consecutive dwords per lane, 4-byte aligned, non-temporal.
 template <int NW>
-__device__ __forceinline__ void load_words_nt(const uint32_t *__restrict__ p, uint32_t (&w)[NW]) {
+__device__ __forceinline__ void load_words_nt(const uint32_t *__restrict__ pg, uint32_t (&w)[NW]) {
+    const gptr<const uint32_t> p = as_global(pg);
     constexpr int Q = NW / 4, R = NW % 4;
     static_for<0, Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        const u32x4a v = __builtin_nontemporal_load(reinterpret_cast<const u32x4a *>(p + 4 * q));
+        const u32x4a v = __builtin_nontemporal_load((gptr<const u32x4a>)(p + 4 * q));
         w[4 * q + 0] = v.x;
         w[4 * q + 1] = v.y;
         w[4 * q + 2] = v.z;
         w[4 * q + 3] = v.w;
     });
     if constexpr (R == 3) {
-        const u32x3a v = __builtin_nontemporal_load(reinterpret_cast<const u32x3a *>(p + 4 * Q));
+        const u32x3a v = __builtin_nontemporal_load((gptr<const u32x3a>)(p + 4 * Q));
         w[4 * Q + 0] = v.x;
         w[4 * Q + 1] = v.y;
         w[4 * Q + 2] = v.z;
     } else if constexpr (R == 2) {
-        const u32x2a v = __builtin_nontemporal_load(reinterpret_cast<const u32x2a *>(p + 4 * Q));
+        const u32x2a v = __builtin_nontemporal_load((gptr<const u32x2a>)(p + 4 * Q));
         w[4 * Q + 0] = v.x;
         w[4 * Q + 1] = v.y;
     } else if constexpr (R == 1) {

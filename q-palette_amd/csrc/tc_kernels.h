@@ -60,6 +60,11 @@ struct TcParams {
     const uint16_t *wscale;  // gemv epilogue: fp16 [m] per-output-row scale or null
     float oscale;            // gemv epilogue: out = acc * wscale[row] * oscale
     unsigned long long *dbg;  // QPAL_STAMPS diagnostic builds only: per-wave s_memtime stamps
+    // chain launches only (tc_chain.h): data handed from phase to phase inside one launch
+    const float *x_f32;      // staged x = fp16(x_f32[i] * x_f32_scale): the fp32 output of an earlier phase (agent-scope loads)
+    float x_f32_scale;
+    int x_fresh;             // x (fp16) was written by an earlier phase of this launch: agent-scope loads
+    int publish;             // out is read by a later phase of this launch: agent-scope (write-through) stores
 };
 
 constexpr int kMaxJobs = 8;
@@ -106,7 +111,7 @@ struct TcqCodec {
     static constexpr int CHUNKS = LDS_DWORDS / 4;  // 16-byte chunks: conflict-free ds_write_b128
     // image entry e (sign flag folded in) from the codebook in memory
     static __device__ __forceinline__ uint32_t entry(const void *tab, int e) {
-        return static_cast<const uint32_t *>(tab)[e & ((1 << S) - 1)] ^ (((uint32_t)e >> S) << 15);
+        return as_global(static_cast<const uint32_t *>(tab))[e & ((1 << S) - 1)] ^ (((uint32_t)e >> S) << 15);
     }
     static __device__ __forceinline__ void build(uint32_t *lds, const void *tab, int tid, int nthreads) {
         for (int c = tid; c < CHUNKS; c += nthreads) {
@@ -193,8 +198,8 @@ struct LutCodec {
 
     static constexpr int CHUNKS = LDS_DWORDS / 4;
     static __device__ __forceinline__ uint32_t entry(const void *tab, int e) {
-        const uint16_t *__restrict__ l16 = static_cast<const uint16_t *>(tab);
-        const uint32_t *__restrict__ l32 = static_cast<const uint32_t *>(tab);
+        const gptr<const uint16_t> l16 = as_global(static_cast<const uint16_t *>(tab));
+        const gptr<const uint32_t> l32 = as_global(static_cast<const uint32_t *>(tab));
         if constexpr (VEC == 2) return l32[e];
         else if constexpr (PAIR) return (uint32_t)l16[e & ((1 << BITS) - 1)] | ((uint32_t)l16[e >> BITS] << 16);
         else return l16[e];
