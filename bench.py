@@ -54,12 +54,13 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--streams", type=int, default=1,
                     help="1: every GEMV on one stream; 3: q|k|v and gate|up fork onto side streams inside the graph")
-    ap.add_argument("--launch", default="chain", choices=["single", "multi", "chain"],
-                    help="single: one launch per linear (7/layer); multi: q|k|v and gate|up (projections of one input) "
-                         "go out as one multi-job launch each (4 launches/layer, same arithmetic, same buffers); chain "
-                         "(default): the same multi-job GEMVs as PHASES of one persistent launch per run of equal codecs — "
-                         "stream order between phases kept by an in-kernel arrival counter (csrc/tc_chain.h); phases no "
-                         "chain can take (SIMT packing, mixed codecs in one phase, batch > 8) run as multi-job launches")
+    ap.add_argument("--launch", default="multi", choices=["single", "multi", "chain"],
+                    help="single: one launch per linear (7/layer); multi (default, the fastest measured): q|k|v and gate|up "
+                         "(projections of one input) go out as one multi-job launch each (4 launches/layer, same arithmetic, "
+                         "same buffers); chain: the same multi-job GEMVs as PHASES of one persistent launch per run of equal "
+                         "codecs — stream order between phases kept by an in-kernel arrival counter (csrc/tc_chain.h; measured "
+                         "10-15 %% slower than multi: DESIGN.md §4.6); phases no chain can take (SIMT packing, mixed codecs in "
+                         "one phase, batch > 8) run as multi-job launches")
     ap.add_argument("--distinct-codebooks", action="store_true",
                     help="give every linear its own random codebook (default: one codebook per model, as in real "
                          "Q-Palette checkpoints where every layer stores a copy of the same k-means codebook)")

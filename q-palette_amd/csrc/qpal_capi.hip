@@ -156,9 +156,10 @@ bool plan_chain_phase(TcMultiParams &mp, const int *out_zeroed, int ncu) {
         if (st < min_st) min_st = st;
         two = two || mp.job[j].st2 > 0;
     }
-    int log2_wpr = 3;
+    constexpr int kMinSteps = kChainG > 1 ? kChainG : 1;  // the kernel's decode-ahead depth: a shorter chunk leaves slots dead
+    int log2_wpr = kChainLog2W;
     while (log2_wpr > 0 && items_at(mp, log2_wpr, W) > ncu) log2_wpr--;
-    while (log2_wpr > 0 && (1 << log2_wpr) > min_st) log2_wpr--;
+    while (log2_wpr > 0 && (min_st >> log2_wpr) < kMinSteps) log2_wpr--;
     if (two && log2_wpr == 0) log2_wpr = 1;
     const int items = items_at(mp, log2_wpr, W);
     if (items > ncu) return false;
@@ -166,9 +167,9 @@ bool plan_chain_phase(TcMultiParams &mp, const int *out_zeroed, int ncu) {
         TcParams &p = mp.job[j];
         int sk = 1;
         const int per_wave = (p.st1 + p.st2 + (1 << log2_wpr) - 1) >> log2_wpr;
-        if (items * 2 <= ncu && log2_wpr == 3 && out_zeroed[j]) {
+        if (items * 2 <= ncu && log2_wpr == kChainLog2W && out_zeroed[j]) {
             const int want = ncu / items;
-            while (sk * 2 <= want && per_wave / (sk * 2) >= 1) sk *= 2;
+            while (sk * 2 <= want && per_wave / (sk * 2) >= kMinSteps) sk *= 2;
         }
         set_chunks(p, log2_wpr, sk, W);
     }
@@ -551,7 +552,7 @@ static int chain_build(void *host_blob, long blob_bytes, const qpal_chain_phase 
             p.x_f32_scale = x_f32_scale == 0.0f ? 1.0f : x_f32_scale;
             p.x_fresh = x_fresh || x_f32 != nullptr;
             p.publish = publish;
-            if (p.x_fresh && !p.x_lds) return QPAL_E_SHAPE;  // in-launch activations are staged through LDS only
+            if (!p.x_lds) return QPAL_E_SHAPE;  // the chain kernel stages the activations through LDS only
         }
         // all jobs of a phase share one input: one staging per workgroup
         for (int j = 1; j < cp.njobs; j++) {

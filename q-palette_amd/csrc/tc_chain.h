@@ -27,8 +27,30 @@
 
 namespace qpal {
 
-constexpr int kChainWaves = 8;
+// Shape knobs (perf experiments override them with -D; the defaults are what measured best):
+//   W waves per workgroup (8: 2 per SIMD, 256 VGPRs; 16: 4 per SIMD, 128 VGPRs), G steps decoded ahead of the dependency
+//   (32 VGPRs of A fragments each), R ring slots of packed steps (prefetch distance, ~8 VGPRs each), PAIRS: the steady
+//   state runs two interleaved steps (more ILP for 2 waves per SIMD, ~60 VGPRs)
+#ifndef QPAL_CHAIN_W
+#define QPAL_CHAIN_W 16
+#endif
+#ifndef QPAL_CHAIN_G
+#define QPAL_CHAIN_G 0
+#endif
+#ifndef QPAL_CHAIN_R
+#define QPAL_CHAIN_R 2
+#endif
+#ifndef QPAL_CHAIN_PAIRS
+#define QPAL_CHAIN_PAIRS 0
+#endif
+constexpr int kChainWaves = QPAL_CHAIN_W;
+constexpr int kChainLog2W = kChainWaves == 16 ? 4 : 3;
+static_assert(kChainWaves == 8 || kChainWaves == 16, "waves per workgroup");
 constexpr int kChainThreads = 64 * kChainWaves;
+constexpr int kChainG = QPAL_CHAIN_G;
+constexpr int kChainR = QPAL_CHAIN_R;
+static_assert(kChainG <= kChainR && kChainR >= 2, "ring");
+constexpr bool kChainPairs = QPAL_CHAIN_PAIRS != 0 && kChainR % 2 == 0 && kChainG % 2 == 0;
 constexpr int kChainShards = 8;
 constexpr unsigned kChainGuard = 1u << 21;  // polls before a wait gives up and reports (never hang the GPU)
 
@@ -57,19 +79,6 @@ template <class C>
 constexpr int chain_scratch_bytes() {
     constexpr int avail = 160 * 1024 - C::LDS_DWORDS * 4 - 1024;
     return avail > 72 * 1024 ? 72 * 1024 : avail;
-}
-
-// steps per group = decoded ahead of the dependency = prefetch distance: 4 (128 VGPRs of A fragments); 2 for the codecs
-// with more than 10 packed dwords per lane and step (8-bit scalar codes: 16)
-template <class C1, class C2>
-constexpr int chain_group() {
-    int nw = C1::NW;
-    if constexpr (!std::is_void_v<C2>) nw = C2::NW > nw ? C2::NW : nw;
-#ifdef QPAL_CHAIN_G
-    return QPAL_CHAIN_G;
-#else
-    return nw > 10 ? 2 : 4;
-#endif
 }
 
 template <class Codec>
@@ -101,49 +110,122 @@ __device__ __forceinline__ void mfma_step(const half8_t (&af)[8], const u32x4 (&
     });
 }
 
+// Ring slots are plain uint32_t[NWMAX] arrays; the codecs see their own uint32_t[NW] copies (register renames once the
+// arrays are scalarised — a reinterpret_cast view of a slot kept the whole ring in scratch memory instead).
+template <int NWMAX>
+using slot_t = uint32_t __attribute__((ext_vector_type(NWMAX)));  // a first-class value: always registers
+
 template <int NW, int NWMAX>
-__device__ __forceinline__ uint32_t (&words(uint32_t (&w)[NWMAX]))[NW] {
+__device__ __forceinline__ void slot_load(const StreamView &sv, int step, int lane, slot_t<NWMAX> &slot) {
     static_assert(NW <= NWMAX, "codec words");
-    return reinterpret_cast<uint32_t(&)[NW]>(w);
+    uint32_t t[NW];
+    load_step_w<NW>(sv, step, lane, t);
+    slot_t<NWMAX> v = slot;
+    static_for<0, NW>([&](auto ic) { v[decltype(ic)::value] = t[decltype(ic)::value]; });
+    slot = v;
+}
+template <class Codec, int NWMAX>
+__device__ __forceinline__ void slot_decode(const uint32_t *lut, uint32_t laneoff, const slot_t<NWMAX> &slot, half8_t (&af)[8]) {
+    uint32_t w[Codec::NW];
+    static_for<0, Codec::NW>([&](auto ic) { w[decltype(ic)::value] = slot[decltype(ic)::value]; });
+    decode_step<Codec>(lut, laneoff, w, af);
+}
+template <class Codec, int NWMAX>
+__device__ __forceinline__ void slot_gemv(const uint32_t *lut, uint32_t laneoff, const slot_t<NWMAX> &slot,
+                                          const u32x4 (&xb)[1][2], Acc<1> &acc) {
+    uint32_t w[Codec::NW];
+    static_for<0, Codec::NW>([&](auto ic) { w[decltype(ic)::value] = slot[decltype(ic)::value]; });
+    gemv_step<Codec, 1>(lut, laneoff, w, xb, acc);
 }
 
-// Straight-line code per group: every step of a group is decoded whether or not it belongs to the wave's chunk [s0, s1)
-// (branches around whole decode steps made the register allocator merge 32-register fragments over every path: 850
-// spilled VGPRs).  Packed words start as zeros and loads are predicated, so a dead step decodes codebook entry 0
-// (finite) against zero activations; its load is never issued (no extra HBM traffic).
+// A wave's share of one phase (everything wave-uniform).  The packed words of a phase's first G steps are requested while
+// the PREVIOUS phase is still running (ring slots are refilled across the phase boundary), so the context of phase p+1 is
+// computed at the top of phase p.
+struct ChainCtx {
+    const uint32_t *base;  // first dword of the wave's supertile row in its stream
+    int nsc, col0;         // supertile columns of the stream, first x column of the stream
+    int s0, T;             // first step and number of steps of the wave's chunk (T == 0: nothing to do)
+    int on2;               // chunk lies in stream 2 (second codec of a combt layer)
+    int j;                 // job of the workgroup's item
+    int rg, ks;            // row group and K split index of the item
+    int has;               // the workgroup has an item in this phase
+};
 
-// before the dependency: request the first group of steps
-template <class Codec, int G, int NWMAX>
-__device__ __forceinline__ void chain_request(const StreamView &sv, int s0, int s1, int lane, uint32_t (&wq)[G][NWMAX]) {
-    static_for<0, G>([&](auto dc) {
-        constexpr int d = decltype(dc)::value;
+template <bool TWO, int NW1, int NW2>
+__device__ __forceinline__ ChainCtx chain_ctx(const TcMultiParams &mp, int wave) {
+    ChainCtx c{};
+    const int gitem = blockIdx.x;
+    c.has = gitem < mp.total_items;
+    int j = 0, item_begin = 0;
 #pragma unroll
-        for (int i = 0; i < NWMAX; i++) wq[d][i] = 0u;
-        if (s0 + d < s1) load_step_w<Codec::NW>(sv, s0 + d, lane, words<Codec::NW>(wq[d]));
-    });
+    for (int i = 0; i < kMaxJobs - 1; i++) {
+        if (gitem >= mp.item_end[i] && i + 1 < mp.njobs) {
+            j = i + 1;
+            item_begin = mp.item_end[i];
+        }
+    }
+    c.j = j;
+    const TcParams &p = mp.job[j];
+    const int log2_wpr = p.log2_wpr, wpr = 1 << log2_wpr;
+    const int rloc = wave >> log2_wpr, wr = wave & (wpr - 1), log2_rpw = kChainLog2W - log2_wpr;
+    const int item = gitem - item_begin;
+    int rg = item, ks = 0;
+    if (p.sk > 1) {
+        rg = item / p.sk;
+        ks = item - rg * p.sk;
+    }
+    c.rg = rg;
+    c.ks = ks;
+    const int sr = (rg << log2_rpw) + rloc;
+    const bool live = c.has && sr < p.nrows;
+    const int ch = ks * wpr + wr;
+    const bool on2 = TWO && ch >= p.nc1;
+    const int cc = on2 ? ch - p.nc1 : ch;
+    const int base = on2 ? p.base2 : p.base1, rem = on2 ? p.rem2 : p.rem1;
+    c.on2 = on2;
+    c.s0 = cc * base + (cc < rem ? cc : rem);
+    c.T = live ? base + (cc < rem ? 1 : 0) : 0;
+    if (on2) {
+        c.base = p.c2 + (long)(live ? sr : 0) * p.nsc2 * 16 * NW2;
+        c.nsc = p.nsc2;
+        c.col0 = p.col2;
+    } else {
+        c.base = p.c1 + (long)(live ? sr : 0) * p.nsc1 * 16 * NW1;
+        c.nsc = p.nsc1;
+        c.col0 = 0;
+    }
+    return c;
 }
 
-// before the dependency: decode the first group into MFMA A fragments, request the second group
-template <class Codec, int G, int NWMAX>
-__device__ __forceinline__ void chain_ahead(const uint32_t *lut, uint32_t laneoff, const StreamView &sv, int s0, int s1,
-                                            int lane, uint32_t (&wq)[G][NWMAX], half8_t (&af)[G][8]) {
-    static_for<0, G>([&](auto dc) {
-        constexpr int d = decltype(dc)::value;
-        decode_step<Codec>(lut, laneoff, words<Codec::NW>(wq[d]), af[d]);
-        if (s0 + G + d < s1) load_step_w<Codec::NW>(sv, s0 + G + d, lane, words<Codec::NW>(wq[d]));
-        __builtin_amdgcn_sched_barrier(0);
-    });
+// packed words of step t (< c.T) of a chunk -> ring slot
+template <class C1, class CB, int NWMAX>
+__device__ __forceinline__ void ring_load(const ChainCtx &c, int t, int lane, slot_t<NWMAX> &slot) {
+    const StreamView sv{c.base, c.nsc, c.col0};
+    if (c.on2) slot_load<CB::NW, NWMAX>(sv, c.s0 + t, lane, slot);
+    else slot_load<C1::NW, NWMAX>(sv, c.s0 + t, lane, slot);
+}
+
+// slot d = t % R has just been consumed as step t of `cur`: its next content is cur's step t + R, or — past the end of the
+// chunk — step d of the NEXT phase's chunk (requested a whole phase tail ahead of its use)
+template <class Codec, class C1, class CB, int R, int NWMAX>
+__device__ __forceinline__ void ring_refill(const ChainCtx &cur, const ChainCtx &nxt, int t, int d, int lane, slot_t<NWMAX> &slot) {
+    if (t + R < cur.T) {
+        const StreamView sv{cur.base, cur.nsc, cur.col0};
+        slot_load<Codec::NW, NWMAX>(sv, cur.s0 + t + R, lane, slot);
+    } else if (d < nxt.T) {
+        ring_load<C1, CB, NWMAX>(nxt, d, lane, slot);
+    }
 }
 
 // activations of step `step` from the LDS copy; a step outside the wave's chunk reads the zero pad
-__device__ __forceinline__ void chain_x(const StreamView &sv, const uint16_t *xs, int k, int n, int zero_off, int step, bool valid,
-                                        int lane, u32x4 (&xb)[1][2]) {
-    const int sc = step * 4 + (lane >> 4);
-    const bool live = valid && sc < sv.nsc;
-    const int c = lane & 15;
-    int b = c >> 1;
+__device__ __forceinline__ void chain_x(const ChainCtx &c, const uint16_t *xs, int k, int n, int zero_off, int t, int lane,
+                                        u32x4 (&xb)[1][2]) {
+    const int sc = (c.s0 + t) * 4 + (lane >> 4);
+    const bool live = t < c.T && sc < c.nsc;
+    const int cl = lane & 15;
+    int b = cl >> 1;
     b = b < n ? b : n - 1;
-    const int off = b * k + sv.col0 + sc * 32 + 4 * (c & 1);
+    const int off = b * k + c.col0 + sc * 32 + 4 * (cl & 1);
     const uint16_t *row = xs + (live ? off : zero_off);
 #pragma unroll
     for (int ksub = 0; ksub < 2; ksub++) {
@@ -153,26 +235,71 @@ __device__ __forceinline__ void chain_x(const StreamView &sv, const uint16_t *xs
     }
 }
 
-// after the dependency: MACs of the decoded group, then the remaining groups (decode + MACs, next group in flight)
-template <class Codec, int G, int NWMAX>
-__device__ __forceinline__ void chain_run(const uint32_t *lut, uint32_t laneoff, const StreamView &sv, const uint16_t *xs, int k,
-                                          int n, int zero_off, int s0, int s1, int lane, uint32_t (&wq)[G][NWMAX],
-                                          const half8_t (&af)[G][8], Acc<1> &acc) {
+// before the dependency: decode the chunk's first G steps into MFMA A fragments; every consumed slot is refilled at once
+template <class Codec, class C1, class CB, int G, int R, int NWMAX>
+__device__ __forceinline__ void chain_ahead(const uint32_t *lut, uint32_t laneoff, const ChainCtx &cur, const ChainCtx &nxt,
+                                            int lane, slot_t<NWMAX> (&wq)[R], half8_t (&af)[G > 0 ? G : 1][8]) {
+    static_for<0, G>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        // unconditional: a branch around a step that DEFINES 32 fragment registers made the allocator spill hundreds of
+        // VGPRs.  A slot the chunk does not use (T < G: the planner avoids it) still holds words that arrived long ago
+        // (its request for the next phase goes out after this function), decodes to finite values and meets zero
+        // activations.
+        slot_decode<Codec, NWMAX>(lut, laneoff, wq[d], af[d]);
+        if (d < cur.T) ring_refill<Codec, C1, CB, R, NWMAX>(cur, nxt, d, d, lane, wq[d]);
+    });
+}
+
+// after the dependency: MACs of the decoded steps, then the rest of the chunk (decode + MACs, R steps in flight)
+template <class Codec, class C1, class CB, int G, int R, bool PAIRS, int NWMAX>
+__device__ __forceinline__ void chain_run(const uint32_t *lut, uint32_t laneoff, const ChainCtx &cur, const ChainCtx &nxt,
+                                          const uint16_t *xs, int k, int n, int zero_off, int lane, slot_t<NWMAX> (&wq)[R],
+                                          const half8_t (&af)[G > 0 ? G : 1][8], Acc<1> &acc) {
     static_for<0, G>([&](auto dc) {
         constexpr int d = decltype(dc)::value;
         u32x4 xb[1][2];
-        chain_x(sv, xs, k, n, zero_off, s0 + d, s0 + d < s1, lane, xb);
+        chain_x(cur, xs, k, n, zero_off, d, lane, xb);  // zero pad for d >= T
         mfma_step(af[d], xb, acc);
     });
-    for (int g = s0 + G; g < s1; g += G) {
-        static_for<0, G>([&](auto dc) {
-            constexpr int d = decltype(dc)::value;
+    auto one = [&](auto dc, int t) {
+        constexpr int d = decltype(dc)::value;
+        if (t < cur.T) {
+#ifdef QPAL_CHAIN_PRIO
+            // "least progress first": the SIMD arbiter serves the highest priority, then the oldest wave — left alone, the
+            // same waves always win and the losers run their steps alone at the end (1-wave issue rate, cold prefetch)
+            {
+                const int left = ((cur.T - t) * 4 - 1) / cur.T;  // 3 .. 0
+                if (left >= 3) __builtin_amdgcn_s_setprio(3);
+                else if (left == 2) __builtin_amdgcn_s_setprio(2);
+                else if (left == 1) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
             u32x4 xb[1][2];
-            chain_x(sv, xs, k, n, zero_off, g + d, g + d < s1, lane, xb);
-            gemv_step<Codec, 1>(lut, laneoff, words<Codec::NW>(wq[d]), xb, acc);
-            if (g + G + d < s1) load_step_w<Codec::NW>(sv, g + G + d, lane, words<Codec::NW>(wq[d]));
-            __builtin_amdgcn_sched_barrier(0);
-        });
+            chain_x(cur, xs, k, n, zero_off, t, lane, xb);
+            slot_gemv<Codec, NWMAX>(lut, laneoff, wq[d], xb, acc);
+            ring_refill<Codec, C1, CB, R, NWMAX>(cur, nxt, t, d, lane, wq[d]);
+        }
+    };
+    // first trip: slots G .. R-1 (slots 0 .. G-1 were decoded ahead)
+    static_for<G, R>([&](auto dc) { one(dc, decltype(dc)::value); });
+    for (int t0 = R; t0 < cur.T; t0 += R) {
+        if (PAIRS && t0 + R <= cur.T) {
+            // full trips as straight-line PAIRS of steps: two waves per SIMD do not hide the LDS gather latency of one
+            // step, the second step's address arithmetic does
+            static_for<0, R / 2>([&](auto dc) {
+                constexpr int d = 2 * decltype(dc)::value;
+                u32x4 xa[1][2], xb[1][2];
+                chain_x(cur, xs, k, n, zero_off, t0 + d, lane, xa);
+                chain_x(cur, xs, k, n, zero_off, t0 + d + 1, lane, xb);
+                slot_gemv<Codec, NWMAX>(lut, laneoff, wq[d], xa, acc);
+                slot_gemv<Codec, NWMAX>(lut, laneoff, wq[d + 1], xb, acc);
+                ring_refill<Codec, C1, CB, R, NWMAX>(cur, nxt, t0 + d, d, lane, wq[d]);
+                ring_refill<Codec, C1, CB, R, NWMAX>(cur, nxt, t0 + d + 1, d + 1, lane, wq[d + 1]);
+            });
+        } else {
+            static_for<0, R>([&](auto dc) { one(dc, t0 + decltype(dc)::value); });
+        }
     }
 }
 
@@ -196,7 +323,7 @@ __global__ __launch_bounds__(kChainThreads) void tc_chain_kernel(const TcMultiPa
     using CB = std::conditional_t<TWO, C2, C1>;
     constexpr int NWMAX = C1::NW > CB::NW ? C1::NW : CB::NW;
     constexpr int SCR = chain_scratch_bytes<C1>();
-    constexpr int G = chain_group<C1, C2>();
+    constexpr int G = kChainG, R = kChainR;
     __shared__ __attribute__((aligned(16))) uint32_t lut[C1::LDS_DWORDS];
     __shared__ __attribute__((aligned(16))) unsigned char scratch[SCR];
     __shared__ unsigned wave_ctr;
@@ -211,65 +338,49 @@ __global__ __launch_bounds__(kChainThreads) void tc_chain_kernel(const TcMultiPa
     const unsigned seq0 = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_agent(&ws->epoch));
     const void *cur_tab = nullptr;
 
+    slot_t<NWMAX> wq[R];  // ring of packed steps: slot d holds steps d, d + R, ... of the current chunk, then step d of the next
+    static_for<0, R>([&](auto dc) { wq[decltype(dc)::value] = slot_t<NWMAX>(0u); });
+    ChainCtx nxt = chain_ctx<TWO, C1::NW, CB::NW>(phases[0], wave);
+    static_for<0, R>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        if (d < nxt.T) ring_load<C1, CB, NWMAX>(nxt, d, lane, wq[d]);
+    });
+
     for (int ph = 0; ph < nphases; ph++) {
         const TcMultiParams &mp = phases[ph];
-        const int gitem = blockIdx.x;
-        const int total_items = mp.total_items;
-        const bool has = gitem < total_items;  // workgroup-uniform
+        const ChainCtx cur = nxt;
+        nxt = ChainCtx{};
+        if (ph + 1 < nphases) nxt = chain_ctx<TWO, C1::NW, CB::NW>(phases[ph + 1], wave);
+        const bool has = cur.has;  // workgroup-uniform
         QPAL_CSTAMP(0);
 
         // ---------------------------------------------------------------- A: everything that does not need x
-        int j = 0, item_begin = 0;
-#pragma unroll
-        for (int i = 0; i < kMaxJobs - 1; i++) {
-            if (gitem >= mp.item_end[i] && i + 1 < mp.njobs) {
-                j = i + 1;
-                item_begin = mp.item_end[i];
-            }
-        }
-        const TcParams &p = mp.job[j];
+        const TcParams &p = mp.job[cur.j];
         const int n = p.n, k = p.k;
         const int log2_wpr = p.log2_wpr;
         const int wpr = 1 << log2_wpr;
-        const int rloc = wave >> log2_wpr;
-        const int wr = wave & (wpr - 1);
-        const int log2_rpw = 3 - log2_wpr;
+        const int log2_rpw = kChainLog2W - log2_wpr;
         const int zero_off = n * k;
-        float *red = reinterpret_cast<float *>(scratch);                                  // [8][n][32]
+        const int rg = cur.rg;
+        float *red = reinterpret_cast<float *>(scratch);                                  // [W][n][32]
         uint16_t *xs = reinterpret_cast<uint16_t *>(scratch + kChainWaves * 32 * 4 * n);  // [n][k] + 32 zero halves
-        const int item = gitem - item_begin;
-        int rg = item, ks = 0;
-        if (p.sk > 1) {
-            rg = item / p.sk;
-            ks = item - rg * p.sk;
-        }
-        const int sr = (rg << log2_rpw) + rloc;
-        const bool live = has && sr < p.nrows;
         uint32_t wraw = 0;
         if (has && p.wscale && tid < (32 << log2_rpw) && (rg << log2_rpw) + (tid >> 5) < p.nrows)
             wraw = as_global(p.wscale)[((rg << log2_rpw) + (tid >> 5)) * 32 + (tid & 31)];
-        const int c = ks * wpr + wr;
-        const bool on2 = TWO && c >= p.nc1;
-        const int cc = on2 ? c - p.nc1 : c;
-        const int base = on2 ? p.base2 : p.base1, rem = on2 ? p.rem2 : p.rem1;
-        int s0 = cc * base + (cc < rem ? cc : rem);
-        int s1 = s0 + base + (cc < rem ? 1 : 0);
-        if (!live) s0 = s1 = 0;
-        const StreamView sv1{p.c1 + (long)(live ? sr : 0) * p.nsc1 * 16 * C1::NW, p.nsc1, 0};
-        const StreamView sv2{TWO ? p.c2 + (long)(live ? sr : 0) * p.nsc2 * 16 * CB::NW : p.c1, TWO ? p.nsc2 : p.nsc1,
-                             p.col2};
-        uint32_t wq[G][NWMAX];
-        half8_t af[G][8];
-        if (on2) chain_request<CB, G, NWMAX>(sv2, s0, s1, lane, wq);
-        else chain_request<C1, G, NWMAX>(sv1, s0, s1, lane, wq);
         if (has && p.tab != cur_tab) {  // workgroup-uniform; every wave is past the previous phase's decode (reduce barrier)
             C1::build(lut, p.tab, tid, kChainThreads);
             cur_tab = p.tab;
             __syncthreads();
         }
         QPAL_CSTAMP(1);
-        if (on2) chain_ahead<CB, G, NWMAX>(lut, laneoff, sv2, s0, s1, lane, wq, af);
-        else chain_ahead<C1, G, NWMAX>(lut, laneoff, sv1, s0, s1, lane, wq, af);
+        half8_t af[G > 0 ? G : 1][8];
+        if (cur.on2) chain_ahead<CB, C1, CB, G, R, NWMAX>(lut, laneoff, cur, nxt, lane, wq, af);
+        else chain_ahead<C1, C1, CB, G, R, NWMAX>(lut, laneoff, cur, nxt, lane, wq, af);
+        // ring slots this chunk does not use go to the next phase now
+        static_for<0, R>([&](auto dc) {
+            constexpr int d = decltype(dc)::value;
+            if (d >= cur.T && d < nxt.T) ring_load<C1, CB, NWMAX>(nxt, d, lane, wq[d]);
+        });
         QPAL_CSTAMP(2);
 
         // ---------------------------------------------------------------- B: the dependency
@@ -279,9 +390,9 @@ __global__ __launch_bounds__(kChainThreads) void tc_chain_kernel(const TcMultiPa
             if (lane < kChainShards) need = ((gridDim.x + (kChainShards - 1) - lane) / kChainShards) * done;
             unsigned guard = 0;
             for (;;) {
-                unsigned cur = need;
-                if (lane < kChainShards) cur = ld_agent(&ws->shard[lane][0]);
-                if (__all((int)(cur - need) >= 0)) break;
+                unsigned seen = need;
+                if (lane < kChainShards) seen = ld_agent(&ws->shard[lane][0]);
+                if (__all((int)(seen - need) >= 0)) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (++guard > kChainGuard) {
                     if (lane == 0) st_agent(&ws->error, 1u + (unsigned)ph);
@@ -294,7 +405,6 @@ __global__ __launch_bounds__(kChainThreads) void tc_chain_kernel(const TcMultiPa
 
         // ---------------------------------------------------------------- C: activations -> LDS
         if (has) {  // the host plans a chain only where x fits the LDS scratch
-
             const int total = n * k;  // multiple of 8 halves
             if (p.x_f32) {            // x = fp16(src * scale), src written by an earlier phase: agent-scope loads
                 const unsigned *src = reinterpret_cast<const unsigned *>(p.x_f32);
@@ -325,8 +435,11 @@ __global__ __launch_bounds__(kChainThreads) void tc_chain_kernel(const TcMultiPa
         // ---------------------------------------------------------------- D: MACs (+ the steps not decoded ahead)
         Acc<1> acc;
         static_for<0, 4>([&](auto ac) { acc.v[0][decltype(ac)::value] = float4_t{0.f, 0.f, 0.f, 0.f}; });
-        if (on2) chain_run<CB, G, NWMAX>(lut, laneoff, sv2, xs, k, n, zero_off, s0, s1, lane, wq, af, acc);
-        else chain_run<C1, G, NWMAX>(lut, laneoff, sv1, xs, k, n, zero_off, s0, s1, lane, wq, af, acc);
+        if (cur.on2) chain_run<CB, C1, CB, G, R, kChainPairs, NWMAX>(lut, laneoff, cur, nxt, xs, k, n, zero_off, lane, wq, af, acc);
+        else chain_run<C1, C1, CB, G, R, kChainPairs, NWMAX>(lut, laneoff, cur, nxt, xs, k, n, zero_off, lane, wq, af, acc);
+#ifdef QPAL_CHAIN_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         QPAL_CSTAMP(5);
 
         // ---------------------------------------------------------------- E: cross-wave sum, epilogue, arrival
@@ -337,9 +450,9 @@ __global__ __launch_bounds__(kChainThreads) void tc_chain_kernel(const TcMultiPa
             float *dst = red + ((wave * n + (b < n ? b : 0)) * 32) + 2 * q;
             static_for<0, 4>([&](auto ac) {
                 constexpr int a = decltype(ac)::value;
-                const float4_t d = acc.v[0][a];
-                const float v0 = d[0] + __shfl_xor(d[1], 1, 64);
-                const float v1 = d[2] + __shfl_xor(d[3], 1, 64);
+                const float4_t dd = acc.v[0][a];
+                const float v0 = dd[0] + __shfl_xor(dd[1], 1, 64);
+                const float v1 = dd[2] + __shfl_xor(dd[3], 1, 64);
                 if (writer) {
                     dst[8 * a] = v0;
                     dst[8 * a + 1] = v1;
@@ -364,12 +477,14 @@ __global__ __launch_bounds__(kChainThreads) void tc_chain_kernel(const TcMultiPa
                 }
             }
         }
-        // arrival: every wave drains its own stores, the last of the 8 to do so signals for the workgroup
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Arrival: every wave waits for its own stores (but not for the packed words it has already requested for the
+        // next phase: they are younger, and memory operations complete in issue order), the last of the 8 signals.
+        if (tid < (32 << log2_rpw) || mp.zero_chunks > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
             const unsigned old = __hip_atomic_fetch_add(&wave_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if ((old & (kChainWaves - 1)) == kChainWaves - 1)
-                __hip_atomic_fetch_add(&ws->shard[blockIdx.x & (kChainShards - 1)][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(as_global(&ws->shard[blockIdx.x & (kChainShards - 1)][0]), 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
         }
         QPAL_CSTAMP(7);
     }
