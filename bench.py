@@ -38,6 +38,8 @@ WORKLOADS = {
     # the reference's published mixed-scheme results (perf/qdicts/*.json, exported from msq_results/):
     "llama3.1-8b_figure1c": ("3_8b", "qdict:figure1c"),   # latency-aware MSQ, no fusion, avg 2.86 b/w
     "llama3.1-8b_figure1d": ("3_8b", "qdict:figure1d"),   # fusion-aware MSQ (merged qkv/kv + up|gate), avg 2.96 b/w
+    # BASELINE.json configs[2]: memory-constrained MSQ at 3.25 avg bits, mixed TCQ / VQ / SQ (perf/make_mem3p25.py)
+    "llama3.1-8b_mem3p25": ("3_8b", "qdict:mem3p25"),
 }
 LINEAR_ORDER = ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj",
                 "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"]
@@ -104,7 +106,8 @@ def _mi355x_prefers_simt(keys, qstr):
     return tc is not None and simt is not None and simt < tc
 
 
-def build_model(qp, torch, model_key, qstr, nlayers, device, shard=None, distinct_codebooks=False, packing="qdict"):
+def build_model(qp, torch, model_key, qstr, nlayers, device, shard=None, distinct_codebooks=False, packing="qdict",
+                keep_infos=False):
     """-> list over layers of 4 groups [attention inputs (q,k,v), o, mlp inputs (gate,up), down]; a group is a
     list of (module, in_features, linear_info-or-None) that share one input vector.  Every layer has
     distinct packed buffers.  qstr "qdict:<name>": quantizer per linear (+ fused layers) from perf/qdicts."""
@@ -137,7 +140,7 @@ def build_model(qp, torch, model_key, qstr, nlayers, device, shard=None, distinc
             mod = qp.VQLinearPackSIMT.gen_layer_from_info(info, device=device)
         else:
             mod = cls.gen_layer_from_info(info).to(device)
-        return (mod, info["in_features"], info if layer == 0 else None)
+        return (mod, info["in_features"], info if (layer == 0 or keep_infos) else None)
 
     layers = []
     for layer in range(nlayers):
@@ -158,6 +161,86 @@ def build_model(qp, torch, model_key, qstr, nlayers, device, shard=None, distinc
     if not distinct_codebooks:  # what a checkpoint loader does: identical codebooks share one tensor
         qp.share_codebooks([m for groups in layers for grp in groups for m, _, _ in grp])
     return layers
+
+
+def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=False, gather=None, side=(), main_stream=None):
+    """-> (token, parts): token() runs every quantized linear of `layers` once (one decoded token at batch n, plain inputs
+    xs[in_features]) and returns the outputs in model order; parts: the chain / multi-job partition of --launch chain, else
+    None.  Also what tests/test_bench_workloads.py drives for the published mixed-scheme workloads."""
+    parts = None  # --launch chain: GemvChain objects (one launch each) and left-over Phases (multi-job launches)
+    if launch == "chain" and gather is None:
+        Phase = qp.chain.Phase
+        plan = []
+        for groups in layers:
+            pre = {}
+            for gi, grp in enumerate(groups):
+                ph = Phase(layers=[m for m, _, _ in grp], x=xs[grp[0][1]])
+                if gi in (0, 2) and not no_prezero and len(groups[gi + 1]) == 1:
+                    pre[gi + 1] = torch.empty((n, groups[gi + 1][0][0].out_features), dtype=torch.float32, device=device)
+                    ph.prezero = pre[gi + 1]
+                elif gi in pre:
+                    ph.outs, ph.outs_zeroed = [pre[gi]], True
+                plan.append(ph)
+        parts = qp.chain.build_chains(plan, n, device)
+
+    def token_chain():
+        outs = []
+        for part in parts:
+            if isinstance(part, qp.chain.GemvChain):
+                part.launch()
+                outs += [y for ph in part.phases for y in ph.results]
+            else:
+                outs += qp.multi_gemv(part.layers, part.x, outs=part.outs, outs_zeroed=part.outs_zeroed, prezero=part.prezero)
+        return outs
+
+    def token():
+        if parts is not None:
+            return token_chain()
+        outs = []
+        for groups in layers:
+            pre = {}  # group index -> output buffer zeroed by an earlier launch of this block
+            for gi, grp in enumerate(groups):
+                x = xs[grp[0][1]]
+                mods = [m for m, _, _ in grp]
+                if launch in ("multi", "chain") and gather is None:
+                    # projections of one input: one multi-job launch per codec.  The attention-input / mlp-input
+                    # launches also zero the output of o_proj / down_proj, so that a split-K there (few rows:
+                    # half of the CUs would idle) needs no memset node of its own.
+                    nxt = gi + 1
+                    if gi in (0, 2) and not no_prezero and len(groups[nxt]) == 1:
+                        pre[nxt] = torch.empty((n, groups[nxt][0][0].out_features), dtype=torch.float32, device=device)
+                        outs += qp.multi_gemv(mods, x, prezero=pre[nxt])
+                    elif gi in pre:
+                        outs += qp.multi_gemv(mods, x, outs=[pre[gi]], outs_zeroed=True)
+                    else:
+                        outs += qp.multi_gemv(mods, x)
+                    continue
+                if len(mods) > 1 and side:                # fork/join onto side streams inside the graph
+                    ev = torch.cuda.Event()
+                    ev.record(main_stream)
+                    evs = []
+                    for j, mod in enumerate(mods):
+                        if j == 0:
+                            outs.append(mod._gemv(x, n))
+                            continue
+                        s_ = side[(j - 1) % len(side)]
+                        s_.wait_event(ev)
+                        with torch.cuda.stream(s_):
+                            outs.append(mod._gemv(x, n))
+                            e2 = torch.cuda.Event()
+                            e2.record(s_)
+                            evs.append(e2)
+                    for e2 in evs:
+                        main_stream.wait_event(e2)
+                    continue
+                for mod in mods:
+                    y = mod._gemv(x, n)
+                    if gather is not None and gi in (1, 3):  # o_proj / down_proj feed full-width consumers
+                        y = gather(y)
+                    outs.append(y)
+        return outs
+
+    return token, parts
 
 
 def algorithmic_bytes(qp, layers, batch):
@@ -319,80 +402,11 @@ def main():
                     outs += qp.multi_gemv(mods, xr, **kw)
         return outs
 
-    parts = None  # --launch chain: GemvChain objects (one launch each) and left-over Phases (multi-job launches)
-    if args.launch == "chain" and gather is None and not args.incoherent:
-        Phase = qp.chain.Phase
-        plan = []
-        for groups in layers:
-            pre = {}
-            for gi, grp in enumerate(groups):
-                ph = Phase(layers=[m for m, _, _ in grp], x=xs[grp[0][1]])
-                if gi in (0, 2) and not args.no_prezero and len(groups[gi + 1]) == 1:
-                    pre[gi + 1] = torch.empty((n, groups[gi + 1][0][0].out_features), dtype=torch.float32, device=device)
-                    ph.prezero = pre[gi + 1]
-                elif gi in pre:
-                    ph.outs, ph.outs_zeroed = [pre[gi]], True
-                plan.append(ph)
-        parts = qp.chain.build_chains(plan, n, device)
-
-    def token_chain():
-        outs = []
-        for part in parts:
-            if isinstance(part, qp.chain.GemvChain):
-                part.launch()
-                outs += [y for ph in part.phases for y in ph.results]
-            else:
-                outs += qp.multi_gemv(part.layers, part.x, outs=part.outs, outs_zeroed=part.outs_zeroed, prezero=part.prezero)
-        return outs
+    plain_token, parts = make_token(qp, torch, layers, xs, n, device, launch=args.launch if not args.incoherent else "multi",
+                                    no_prezero=args.no_prezero, gather=gather, side=side, main_stream=main_stream)
 
     def token():
-        if args.incoherent:
-            return token_incoherent()
-        if parts is not None:
-            return token_chain()
-        outs = []
-        for groups in layers:
-            pre = {}  # group index -> output buffer zeroed by an earlier launch of this block
-            for gi, grp in enumerate(groups):
-                x = xs[grp[0][1]]
-                mods = [m for m, _, _ in grp]
-                if args.launch == "multi" and gather is None:
-                    # projections of one input: one multi-job launch per codec.  The attention-input / mlp-input
-                    # launches also zero the output of o_proj / down_proj, so that a split-K there (few rows:
-                    # half of the CUs would idle) needs no memset node of its own.
-                    nxt = gi + 1
-                    if gi in (0, 2) and not args.no_prezero and len(groups[nxt]) == 1:
-                        pre[nxt] = torch.empty((n, groups[nxt][0][0].out_features), dtype=torch.float32, device=device)
-                        outs += qp.multi_gemv(mods, x, prezero=pre[nxt])
-                    elif gi in pre:
-                        outs += qp.multi_gemv(mods, x, outs=[pre[gi]], outs_zeroed=True)
-                    else:
-                        outs += qp.multi_gemv(mods, x)
-                    continue
-                if len(mods) > 1 and side:                # fork/join onto side streams inside the graph
-                    ev = torch.cuda.Event()
-                    ev.record(main_stream)
-                    evs = []
-                    for j, mod in enumerate(mods):
-                        if j == 0:
-                            outs.append(mod._gemv(x, n))
-                            continue
-                        s_ = side[(j - 1) % len(side)]
-                        s_.wait_event(ev)
-                        with torch.cuda.stream(s_):
-                            outs.append(mod._gemv(x, n))
-                            e2 = torch.cuda.Event()
-                            e2.record(s_)
-                            evs.append(e2)
-                    for e2 in evs:
-                        main_stream.wait_event(e2)
-                    continue
-                for mod in mods:
-                    y = mod._gemv(x, n)
-                    if gather is not None and gi in (1, 3):  # o_proj / down_proj feed full-width consumers
-                        y = gather(y)
-                    outs.append(y)
-        return outs
+        return token_incoherent() if args.incoherent else plain_token()
 
     graph = None
     with torch.cuda.stream(main_stream):

@@ -439,12 +439,16 @@ int launch_hadamard(const HadParams &p, hipStream_t stream) {
     if (p.hd <= 4096) {  // <= 256 groups of 16: four waves do it
         hipLaunchKernelGGL((had_kernel<256>), dim3(grid), dim3(256), lds, stream, p);
     } else {
-        static bool attr_set = false;
-        if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in (idempotent; races are harmless)
+        // > 64 KiB of dynamic LDS needs the opt-in, per DEVICE (function attributes belong to the device's code object);
+        // idempotent, races are harmless
+        static bool attr_set[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+        if (dev < 0 || !attr_set[dev]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&had_kernel<768>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
-            attr_set = true;
+            if (dev >= 0) attr_set[dev] = true;
         }
         hipLaunchKernelGGL((had_kernel<768>), dim3(grid), dim3(768), lds, stream, p);
     }
@@ -466,7 +470,8 @@ extern "C" int qpal_hadamard(void *out_f16, const void *in, const void *su, cons
     if (out_f16 == in) return QPAL_E_PARAM;  // not in place: the waves of a block read all of it while others already write
     if (K < 1 || K > 256 || (K > 1 && !hadk)) return K > 1 && !hadk ? QPAL_E_NULL : QPAL_E_PARAM;
     if (in_mode < QPAL_IN_F16 || in_mode > QPAL_IN_SWIGLU_F32) return QPAL_E_PARAM;
-    if (rows < 1 || rows > 65535 || n < 1 || hd < 1 || n % hd || hd % K) return QPAL_E_SHAPE;
+    if (rows < 1 || n < 1 || hd < 1 || n % hd || hd % K) return QPAL_E_SHAPE;
+    if ((long)rows * (n / hd) > 0x7fffffffL || (long)rows * n / 16 > 0x7fffffffL) return QPAL_E_SHAPE;  // 1-D grids: one workgroup per block / per 4 column tiles
     const int P = hd / K;
     if (P & (P - 1)) return QPAL_E_SHAPE;
     if (K > 1 && P < 16) return QPAL_E_SHAPE;

@@ -310,6 +310,12 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         if (rc) return rc;
         zeroed[j] = jb.out_zeroed;
     }
+    // the kernel stages (or rotates) x once per distinct x pointer: jobs that share x must agree on how
+    for (int j = 1; j < njobs; j++)
+        for (int i = 0; i < j; i++)
+            if (jobs[i].x == jobs[j].x && (jobs[i].x_had != jobs[j].x_had || jobs[i].x_su != jobs[j].x_su ||
+                                           jobs[i].x_post != jobs[j].x_post || jobs[i].k != jobs[j].k))
+                return QPAL_E_PARAM;
     if (mixed) {
         if (n > 8) return QPAL_E_SHAPE;
         for (int j = 0; j < njobs; j++) {
@@ -414,6 +420,11 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
         if (rc) return rc;
         zeroed[j] = jb.out_zeroed;
     }
+    for (int j = 1; j < njobs; j++)
+        for (int i = 0; i < j; i++)
+            if (jobs[i].x == jobs[j].x && (jobs[i].x_had != jobs[j].x_had || jobs[i].x_su != jobs[j].x_su ||
+                                           jobs[i].x_post != jobs[j].x_post || jobs[i].k != jobs[j].k))
+                return QPAL_E_PARAM;
     mp.zero = static_cast<u32x4 *>(prezero);
     mp.zero_chunks = (int)(prezero_bytes / 16);
     int grid;

@@ -103,18 +103,25 @@ def rotate(x, hd=None, hadK=None, K=1, su=None, sv=None, post_scale=1.0, in_mode
     def vec(t, name):
         if t is None:
             return None
-        if t.dtype != torch.float16 or t.numel() != n or not t.is_cuda or not t.is_contiguous():
-            raise _native.QpalError(f"rotate: {name} must be a contiguous fp16 device vector of {n} elements")
+        if t.dtype != torch.float16 or t.numel() != n or not t.is_cuda or not t.is_contiguous() or t.device != x.device:
+            raise _native.QpalError(f"rotate: {name} must be a contiguous fp16 vector of {n} elements on {x.device}")
         return t.data_ptr()
 
     hk = None
     if K > 1:
-        if hadK is None or hadK.dtype != torch.float16 or tuple(hadK.shape) != (K, K) or not hadK.is_cuda:
-            raise _native.QpalError(f"rotate: hadK must be an fp16 device matrix [{K}, {K}]")
-        hk = hadK.contiguous().data_ptr()
-    _native.check(_native.lib().qpal_hadamard(out.data_ptr(), x.data_ptr(), vec(su, "su"), vec(sv, "sv"), hk, rows, n, hd,
-                                              K, in_mode, 1 if round_mid else 0, float(post_scale),
-                                              torch.cuda.current_stream().cuda_stream), "qpal_hadamard")
+        if (hadK is None or hadK.dtype != torch.float16 or tuple(hadK.shape) != (K, K) or not hadK.is_cuda
+                or hadK.device != x.device):
+            raise _native.QpalError(f"rotate: hadK must be an fp16 matrix [{K}, {K}] on {x.device}")
+        hadK = hadK.contiguous()
+        hk = hadK.data_ptr()
+    if not x.is_cuda or out.device != x.device:
+        raise _native.QpalError("rotate: x and out must live on the same GPU")
+    # launch on x's device and ITS current stream (a module on cuda:N of a device_map'ed model is called while another
+    # device is current: the GEMVs around the rotation already run on cuda:N's stream, ops.py)
+    with torch.cuda.device_of(x):
+        _native.check(_native.lib().qpal_hadamard(out.data_ptr(), x.data_ptr(), vec(su, "su"), vec(sv, "sv"), hk, rows, n, hd,
+                                                  K, in_mode, 1 if round_mid else 0, float(post_scale),
+                                                  torch.cuda.current_stream(x.device).cuda_stream), "qpal_hadamard")
     return out
 
 
