@@ -5,5 +5,5 @@ import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); print('$1 $2', round(d['value'],1), 'tok/s', round(d['ms_per_step'],4), 'ms frac', round(d['roofline']['frac'],4))"; }
-for v in "$@"; do run q-palette_amd/libqpal_hip$v.so ""; done
+for v in "$@"; do run q-palette_amd/libqpal_hip$v.so "--launch chain"; done
 run q-palette_amd/libqpal_hip.so "--launch multi"

@@ -54,9 +54,11 @@ def main():
     (chain,) = qp.chain.build_chains(plan, n, dev)
     grid = torch.cuda.get_device_properties(dev).multi_processor_count
     nph = len(plan)
-    dbg = torch.zeros((nph, grid, int(os.environ.get("QPAL_CHAIN_WAVES", "16")), 8), dtype=torch.int64, device=dev)
+    W = int(os.environ.get("QPAL_CHAIN_WAVES", "16"))
+    dbg_all = torch.zeros(nph * grid * W * 8 + grid * 2, dtype=torch.int64, device=dev)
+    dbg = dbg_all[:nph * grid * W * 8].view(nph, grid, W, 8)
     for _ in range(args.reps):
-        chain.launch(dbg=dbg)
+        chain.launch(dbg=dbg_all)
     torch.cuda.synchronize()
     assert qp.chain.chain_error(dev) == 0
     t = dbg.cpu().numpy().astype(np.float64) / 100.0  # us
@@ -77,8 +79,12 @@ def main():
         print(f"{'':8s} last arrival of previous phase -> dependency seen by the last WG {flag:5.2f} us; -> first x staged {macs_first:5.2f} us; "
               f"MACs phase (first staged -> last done) {a[:, :, 5].max() - a[:, :, 4].min():5.2f} us; tail (last MACs done -> last arrival) "
               f"{end - a[:, :, 5].max():5.2f} us")
+    clk = dbg_all[nph * grid * W * 8:].view(grid, 2).cpu().numpy().astype(np.float64)
+    ghz = clk[:, 0] / clk[:, 1] * 0.1
+    print(f"shader clock over the launch (s_memtime / s_memrealtime): median {np.median(ghz):.3f} GHz, min {ghz.min():.3f}, max {ghz.max():.3f}")
     tot = t[nph - 1][:, :, 7].max() - t[nph - 5][:, :, 7].max()
-    print(f"block total {tot:.2f} us -> {1e6 / (tot * 32):.0f} tokens/s at 32 blocks")
+    if tot > 0:
+        print(f"block total {tot:.2f} us -> {1e6 / (tot * 32):.0f} tokens/s at 32 blocks")
 
 
 if __name__ == "__main__":

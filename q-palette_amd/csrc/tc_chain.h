@@ -43,6 +43,11 @@ namespace qpal {
 #ifndef QPAL_CHAIN_PAIRS
 #define QPAL_CHAIN_PAIRS 0
 #endif
+//   PIPE: software pipeline inside a phase — the decode of step t + G runs beside the MACs of step t (G == R): no wait
+//   between a step's LDS gathers and their use, which is what lets two waves per SIMD keep the VALU busy
+#ifndef QPAL_CHAIN_PIPE
+#define QPAL_CHAIN_PIPE 0
+#endif
 constexpr int kChainWaves = QPAL_CHAIN_W;
 constexpr int kChainLog2W = kChainWaves == 16 ? 4 : 3;
 static_assert(kChainWaves == 8 || kChainWaves == 16, "waves per workgroup");
@@ -51,6 +56,8 @@ constexpr int kChainG = QPAL_CHAIN_G;
 constexpr int kChainR = QPAL_CHAIN_R;
 static_assert(kChainG <= kChainR && kChainR >= 2, "ring");
 constexpr bool kChainPairs = QPAL_CHAIN_PAIRS != 0 && kChainR % 2 == 0 && kChainG % 2 == 0;
+constexpr bool kChainPipe = QPAL_CHAIN_PIPE != 0;
+static_assert(!kChainPipe || (kChainR % kChainG == 0 && kChainG >= 2), "pipelined mode: R a multiple of G");
 constexpr int kChainShards = 8;
 constexpr unsigned kChainGuard = 1u << 21;  // polls before a wait gives up and reports (never hang the GPU)
 
@@ -118,6 +125,14 @@ using slot_t = uint32_t __attribute__((ext_vector_type(NWMAX)));  // a first-cla
 template <int NW, int NWMAX>
 __device__ __forceinline__ void slot_load(const StreamView &sv, int step, int lane, slot_t<NWMAX> &slot) {
     static_assert(NW <= NWMAX, "codec words");
+#ifdef QPAL_TEST_NOLOAD  // timing experiment only (results are garbage): what do the steps cost when no weight is loaded?
+    {
+        slot_t<NWMAX> v = slot;
+        static_for<0, NW>([&](auto ic) { v[decltype(ic)::value] = v[decltype(ic)::value] * 1664525u + 1013904223u + (uint32_t)(step + lane); });
+        slot = v;
+        return;
+    }
+#endif
     uint32_t t[NW];
     load_step_w<NW>(sv, step, lane, t);
     slot_t<NWMAX> v = slot;
@@ -246,8 +261,18 @@ __device__ __forceinline__ void chain_ahead(const uint32_t *lut, uint32_t laneof
         // (its request for the next phase goes out after this function), decodes to finite values and meets zero
         // activations.
         slot_decode<Codec, NWMAX>(lut, laneoff, wq[d], af[d]);
-        if (d < cur.T) ring_refill<Codec, C1, CB, R, NWMAX>(cur, nxt, d, d, lane, wq[d]);
+        if constexpr (!kChainPipe) {
+            if (d < cur.T) ring_refill<Codec, C1, CB, R, NWMAX>(cur, nxt, d, d, lane, wq[d]);
+        } else {
+            __builtin_amdgcn_sched_barrier(0);  // one step at a time: G steps of gathers in flight at once need no more registers
+        }
     });
+    if constexpr (kChainPipe) {
+        static_for<0, G>([&](auto dc) {
+            constexpr int d = decltype(dc)::value;
+            if (d < cur.T) ring_refill<Codec, C1, CB, R, NWMAX>(cur, nxt, d, d, lane, wq[d]);
+        });
+    }
 }
 
 // after the dependency: MACs of the decoded steps, then the rest of the chunk (decode + MACs, R steps in flight)
@@ -303,6 +328,54 @@ __device__ __forceinline__ void chain_run(const uint32_t *lut, uint32_t laneoff,
     }
 }
 
+// Pipelined form (R a multiple of G).  Ring slot = step % R, fragment set = step % G.  On entry af[j] holds decoded step j
+// (j < G) and ring slot s the packed step s (G <= s < R) resp. R + s (s < G).  A full trip of R sub-steps runs, for
+// d = 0 .. R-1: the MACs of step t0 + d (fragments decoded G sub-steps ago, activations read a sub-step ago), then the decode
+// of step t0 + d + G into the same fragment registers, then the refill of the slot just decoded; no instruction of a
+// sub-step waits for one of its own LDS reads.  The tail (fewer than R + G steps left) runs the same sub-steps with
+// uniform branches around the MACs only and, per remaining decode, one switch-free predicate that never DEFINES fragments
+// on one path only: a dead decode is skipped together with the MACs that would read it.
+template <class Codec, class C1, class CB, int G, int R, int NWMAX>
+__device__ __forceinline__ void chain_run_pipe(const uint32_t *lut, uint32_t laneoff, const ChainCtx &cur, const ChainCtx &nxt,
+                                               const uint16_t *xs, int k, int n, int zero_off, int lane, slot_t<NWMAX> (&wq)[R],
+                                               half8_t (&af)[G][8], Acc<1> &acc) {
+    u32x4 xb[1][2];
+    chain_x(cur, xs, k, n, zero_off, 0, lane, xb);
+    int t0 = 0;
+#pragma nounroll
+    for (; t0 + R + G <= cur.T; t0 += R) {  // every MAC and every decode of the trip is live
+        static_for<0, R>([&](auto dc) {
+            constexpr int d = decltype(dc)::value;
+            constexpr int a = d % G, sl = (d + G) % R;
+            u32x4 xn[1][2];
+            chain_x(cur, xs, k, n, zero_off, t0 + d + 1, lane, xn);
+            mfma_step(af[a], xb, acc);
+            // the old fragments are dead before the new ones are born: same registers, no copies on the loop's back edge
+            __builtin_amdgcn_sched_barrier(0);
+            slot_decode<Codec, NWMAX>(lut, laneoff, wq[sl], af[a]);
+            ring_refill<Codec, C1, CB, R, NWMAX>(cur, nxt, t0 + d + G, sl, lane, wq[sl]);
+            xb[0][0] = xn[0][0];
+            xb[0][1] = xn[0][1];
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    // tail: steps t0 .. T-1 (fewer than R + G), fragments of steps t0 .. t0+G-1 are decoded
+    static_for<0, R + G>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        constexpr int a = d % G, sl = (d + G) % R;
+        if (t0 + d < cur.T) {
+            chain_x(cur, xs, k, n, zero_off, t0 + d, lane, xb);
+            mfma_step(af[a], xb, acc);
+            if (t0 + d + G < cur.T) {  // af[a] is next read by the MACs of step t0 + d + G, inside this same predicate chain
+                slot_decode<Codec, NWMAX>(lut, laneoff, wq[sl], af[a]);
+                ring_refill<Codec, C1, CB, R, NWMAX>(cur, nxt, t0 + d + G, sl, lane, wq[sl]);
+            }
+        }
+    });
+    if (cur.T < G) {  // fragments the chunk never used were decoded ahead unconditionally: nothing read them
+    }
+}
+
 __device__ __forceinline__ unsigned ld_agent(const unsigned *p) {
     return __hip_atomic_load(as_global(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -324,9 +397,17 @@ __global__ __launch_bounds__(kChainThreads) void tc_chain_kernel(const TcMultiPa
     constexpr int NWMAX = C1::NW > CB::NW ? C1::NW : CB::NW;
     constexpr int SCR = chain_scratch_bytes<C1>();
     constexpr int G = kChainG, R = kChainR;
-    __shared__ __attribute__((aligned(16))) uint32_t lut[C1::LDS_DWORDS];
-    __shared__ __attribute__((aligned(16))) unsigned char scratch[SCR];
-    __shared__ unsigned wave_ctr;
+    // ONE shared object with the codebook image first: at LDS address 0 the gather address is a single v_and_or_b32
+    // (image anywhere else: v_and_b32 + v_add_u32 per weight pair, +32 VALU instructions per step — measured)
+    struct Shared {
+        uint32_t lut[C1::LDS_DWORDS];
+        unsigned char scratch[SCR];
+        unsigned wave_ctr;
+    };
+    __shared__ __attribute__((aligned(16))) Shared sh;
+    uint32_t *const lut = sh.lut;
+    unsigned char *const scratch = sh.scratch;
+    unsigned &wave_ctr = sh.wave_ctr;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -337,6 +418,9 @@ __global__ __launch_bounds__(kChainThreads) void tc_chain_kernel(const TcMultiPa
     // the new value is harmless)
     const unsigned seq0 = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_agent(&ws->epoch));
     const void *cur_tab = nullptr;
+#ifdef QPAL_STAMPS
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     slot_t<NWMAX> wq[R];  // ring of packed steps: slot d holds steps d, d + R, ... of the current chunk, then step d of the next
     static_for<0, R>([&](auto dc) { wq[decltype(dc)::value] = slot_t<NWMAX>(0u); });
@@ -435,8 +519,13 @@ __global__ __launch_bounds__(kChainThreads) void tc_chain_kernel(const TcMultiPa
         // ---------------------------------------------------------------- D: MACs (+ the steps not decoded ahead)
         Acc<1> acc;
         static_for<0, 4>([&](auto ac) { acc.v[0][decltype(ac)::value] = float4_t{0.f, 0.f, 0.f, 0.f}; });
-        if (cur.on2) chain_run<CB, C1, CB, G, R, kChainPairs, NWMAX>(lut, laneoff, cur, nxt, xs, k, n, zero_off, lane, wq, af, acc);
-        else chain_run<C1, C1, CB, G, R, kChainPairs, NWMAX>(lut, laneoff, cur, nxt, xs, k, n, zero_off, lane, wq, af, acc);
+        if constexpr (kChainPipe) {
+            if (cur.on2) chain_run_pipe<CB, C1, CB, G, R, NWMAX>(lut, laneoff, cur, nxt, xs, k, n, zero_off, lane, wq, af, acc);
+            else chain_run_pipe<C1, C1, CB, G, R, NWMAX>(lut, laneoff, cur, nxt, xs, k, n, zero_off, lane, wq, af, acc);
+        } else {
+            if (cur.on2) chain_run<CB, C1, CB, G, R, kChainPairs, NWMAX>(lut, laneoff, cur, nxt, xs, k, n, zero_off, lane, wq, af, acc);
+            else chain_run<C1, C1, CB, G, R, kChainPairs, NWMAX>(lut, laneoff, cur, nxt, xs, k, n, zero_off, lane, wq, af, acc);
+        }
 #ifdef QPAL_CHAIN_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -489,6 +578,13 @@ __global__ __launch_bounds__(kChainThreads) void tc_chain_kernel(const TcMultiPa
         QPAL_CSTAMP(7);
     }
     if (blockIdx.x == 0 && tid == 0) st_agent(&ws->epoch, seq0 + (unsigned)nphases);
+#ifdef QPAL_STAMPS
+    if (dbg && tid == 0) {  // shader clock held by this CU over the launch: (memtime ticks) / (100 MHz realtime ticks)
+        unsigned long long *c = dbg + (long)nphases * gridDim.x * kChainWaves * 8 + blockIdx.x * 2;
+        c[0] = __builtin_amdgcn_s_memtime() - clk0;
+        c[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+#endif
 }
 
 }  // namespace qpal
