@@ -19,6 +19,15 @@ class PackedLinearBase(nn.Module):
     def get_weight(self):  # -> fp16 [m, k]
         raise NotImplementedError
 
+    def op_names(self):
+        """Every ``torch.ops.ours_lib`` name this module's forward can request."""
+        raise NotImplementedError
+
+    def register_ops(self):
+        """Called at the end of every constructor: the operators exist before the first forward / trace / capture
+        (the reference registers its ~12k names eagerly at import, lib/linear/__init__.py:42-420)."""
+        ops.register_names(self.op_names())
+
     def forward(self, inp, **kwargs):
         x = inp.reshape(-1, self.in_features)
         bs = x.shape[0]

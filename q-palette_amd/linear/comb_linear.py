@@ -64,6 +64,15 @@ class CombLinearTCQ(_CombBase):
         self.out_part = tuple(out_part)
         self.register_buffer("trellis1", _trellis_buffer(out_part[0], in_features, KV[0]))
         self.register_buffer("trellis2", _trellis_buffer(out_part[1], in_features, KV[1]))
+        self.register_ops()
+
+    def op_names(self):
+        k, S, (kv1, kv2), B = self.in_features, self.tlut_bits, self.KV, range(1, self.max_fused_batch + 1)
+        if self.use_comb_kernel:
+            return [f"decompress_gemm_tcq_comb_{self.out_features}_{bs}_{k}_{S}_{kv1}_{kv2}" for bs in B] + \
+                   [f"decompress_tcq_comb_{S}_{kv1}_{kv2}"]
+        return [f"decompress_gemm_tcq_{self.out_part[i]}_{bs}_{k}_{S}_{kv}" for i, kv in enumerate((kv1, kv2)) for bs in B] + \
+               [f"decompress_tcq_{S}_{kv1}", f"decompress_tcq_{S}_{kv2}"]
 
     def _gemv(self, x, bs):
         k, S, (kv1, kv2) = self.in_features, self.tlut_bits, self.KV
@@ -96,6 +105,14 @@ class CombtLinearTCQ(_CombBase):
         self.in_part = tuple(in_part)
         self.register_buffer("trellis1", _trellis_buffer(out_features, in_part[0], KV[0]))
         self.register_buffer("trellis2", _trellis_buffer(out_features, in_part[1], KV[1]))
+        self.register_ops()
+
+    def op_names(self):
+        m, k, S, (kv1, kv2), B = self.out_features, self.in_features, self.tlut_bits, self.KV, range(1, self.max_fused_batch + 1)
+        if self.use_comb_kernel:
+            return [f"decompress_gemm_tcq_combt_{m}_{bs}_{k}_{S}_{kv1}_{kv2}" for bs in B] + [f"decompress_tcq_combt_{S}_{kv1}_{kv2}"]
+        return [f"decompress_gemm_tcq_{m}_{bs}_{self.in_part[i]}_{S}_{kv}" for i, kv in enumerate((kv1, kv2)) for bs in B] + \
+               [f"decompress_tcq_{S}_{kv1}", f"decompress_tcq_{S}_{kv2}"]
 
     def _gemv(self, x, bs):
         m, k, S, (kv1, kv2) = self.out_features, self.in_features, self.tlut_bits, self.KV

@@ -22,6 +22,12 @@ class QTIPLinearTCQ(PackedLinearBase):
             self.register_buffer("bias", torch.ones(out_features))
         else:
             self.bias = None
+        self.register_ops()
+
+    def op_names(self):
+        m, k, S, KV = self.out_features, self.in_features, self.tlut_bits, self.KV
+        return [f"decompress_gemm_tcq_{m}_{bs}_{k}_{S}_{KV}" for bs in range(1, self.max_fused_batch + 1)] + \
+               [f"decompress_tcq_{S}_{KV}"]
 
     def _info(self):
         return {

@@ -47,6 +47,12 @@ class VQLinearPackTensorCore(_VQBase):
     def __init__(self, in_features, out_features, lut_bits, vec_sz=2, bias=False, dtype=torch.half, device=None):
         super().__init__(in_features, out_features, lut_bits, vec_sz, bias, dtype, device)
         self.vq_type = f"vq{vec_sz}" if vec_sz > 1 else ("sq_dup" if lut_bits <= 4 else "sq")
+        self.register_ops()
+
+    def op_names(self):
+        m, k = self.out_features, self.in_features
+        return [f"decompress_gemm_{m}_{bs}_{k}_{self.lut_bits}_{self.vq_type}" for bs in range(1, self.max_fused_batch + 1)] + \
+               [f"decompress_{self.lut_bits}_{self.vq_type}"]
 
     def _gemv(self, x, bs):
         m, k = self.out_features, self.in_features
@@ -72,6 +78,13 @@ class VQLinearPackSIMT(_VQBase):
 
     def __init__(self, in_features, out_features, lut_bits, vec_sz=1, bias=False, dtype=torch.half, device=None):
         super().__init__(in_features, out_features, lut_bits, vec_sz, bias, dtype, device)
+        self.register_ops()
+
+    def op_names(self):
+        if self.vec_sz == 1:
+            return ["sq_pack_gemm_simt", "sq_pack_dequant_simt"]
+        return [f"vq_pack_gemm_simt_{bs}_{self.vec_sz}_{self.lut_bits}" for bs in range(1, self.max_fused_batch + 1)] + \
+               [f"vq_pack_dequant_simt_{self.vec_sz}_{self.lut_bits}"]
 
     def _gemv(self, x, bs):
         x3 = x.reshape(bs, 1, self.in_features)

@@ -163,3 +163,57 @@ def test_row_shards_decode_as_row_slices():
             r0, r1 = qp.shard.shard_bounds(m, 3, rank)
             part = W(qp.shard.shard_linear_info(info, rank, 3))
             assert np.array_equal(part.view(np.uint16), full[r0:r1].view(np.uint16))
+
+
+def test_module_constructors_register_their_ops_without_the_lazy_hook():
+    """Boundary hardening: with the private-API lazy lookup switched off (QPAL_LAZY_OPS=0) every operator a module's forward
+    asks for already exists after construction, the reference's calling pattern (getattr(torch.ops.ours_lib, f"...") inside
+    forward, lib/linear/tcq_linear.py:64-85) traces through register_fake, and names nobody registered are refused."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+os.environ["QPAL_LAZY_OPS"] = "0"
+sys.path.insert(0, %r)
+import torch
+import qpalette_amd as qp
+assert qp.ops.LAZY_LOOKUP is False
+k, m = 256, 128
+for qstr in ("tcq_6_none_0.9", "tcomb_6_7_0.5_none_0.9", "comb_6_7_0.5_none_0.9", "ldlq_2_8_none_1.0", "ldlq_1_4_none_1.0"):
+    layer = qp.make_linear_from_info(qstr, qp.mem_op.dummy_linear_info(k, m, qstr, seed=1))
+    for name in layer.op_names():
+        getattr(torch.ops.ours_lib, name)          # plain torch lookup, no hook
+try:
+    getattr(torch.ops.ours_lib, "decompress_gemm_tcq_64_1_64_9_4")
+    raise SystemExit("an unregistered name resolved without the lazy hook")
+except AttributeError:
+    pass
+
+class RefStyle(torch.nn.Module):                    # the reference's forward, verbatim pattern
+    def __init__(self, layer):
+        super().__init__()
+        self.l = layer
+    def forward(self, inp):
+        l = self.l
+        x = inp.view(-1, l.in_features)
+        bs = x.shape[0]
+        y = getattr(torch.ops.ours_lib, f"decompress_gemm_tcq_{l.out_features}_{bs}_{l.in_features}_{l.tlut_bits}_{l.KV}")(
+            l.trellis, x.to(torch.float16), l.tlut)
+        return y.view(*inp.shape[:-1], l.out_features).to(inp.dtype)
+
+from torch._subclasses.fake_tensor import FakeTensorMode
+from torch.fx.experimental.proxy_tensor import make_fx
+layer = qp.make_linear_from_info("tcq_6_none_0.9", qp.mem_op.dummy_linear_info(k, m, "tcq_6_none_0.9", seed=1))
+with FakeTensorMode(allow_non_fake_inputs=True) as mode:
+    fl = RefStyle(layer).to("meta")
+    x = torch.empty(3, k, dtype=torch.float16, device="cuda")
+    tre = torch.empty_like(layer.trellis, device="cuda"); tl = torch.empty(512, 2, dtype=torch.float16, device="cuda")
+    def f(tre, x, tl):
+        return getattr(torch.ops.ours_lib, f"decompress_gemm_tcq_{m}_3_{k}_9_6")(tre, x, tl)
+    gm = make_fx(f)(tre, x, tl)
+names = [n.target.__name__ if hasattr(n.target, "__name__") else str(n.target) for n in gm.graph.nodes if n.op == "call_function"]
+assert any("decompress_gemm_tcq_128_3_256_9_6" in str(t) for t in names), names
+print("ok")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

@@ -394,3 +394,63 @@ def test_mixed_kv_projections_share_one_launch(qp, oracle):
         x = torch.randn(12, k, generator=torch.Generator().manual_seed(12)).cuda()
         for (mod, _, _), y in zip(layers, qp.multi_gemv(mods, x)):
             assert torch.allclose(y, mod._gemv(x, 12), rtol=1e-4, atol=1e-4 * float(y.abs().max()))
+
+
+class _RefStyleTCQ(torch.nn.Module):
+    """The reference's QTIPLinearTCQ.forward pattern (lib/linear/tcq_linear.py:64-85): op looked up by name inside forward."""
+
+    def __init__(self, layer):
+        super().__init__()
+        self.l = layer
+
+    def forward(self, inp):
+        l = self.l
+        x = inp.view(-1, l.in_features)
+        bs = x.shape[0]
+        if bs <= 8:
+            y = getattr(torch.ops.ours_lib, f"decompress_gemm_tcq_{l.out_features}_{bs}_{l.in_features}_{l.tlut_bits}_{l.KV}")(
+                l.trellis, x.to(torch.float16), l.tlut)
+        else:
+            dq = getattr(torch.ops.ours_lib, f"decompress_tcq_{l.tlut_bits}_{l.KV}")(l.trellis, l.tlut, l.out_features, l.in_features)
+            y = x.to(dq.dtype) @ dq.T
+        return y.view(*inp.shape[:-1], l.out_features).to(inp.dtype)
+
+
+def test_reference_calling_pattern_under_torch_compile_and_graph_capture(qp, oracle):
+    """eval/measure_latency.py:220-225 compiles the decode step (fullgraph=True) and runs it under CUDA graphs: the ops must
+    trace (register_fake), compile without graph breaks (backend aot_eager — no Triton in this build) and be capturable with
+    the reference's own calling pattern."""
+    qstr, k, m = "tcq_6_none_0.9", 1024, 512
+    info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=3, device="cpu")
+    layer = qp.make_linear_from_info(qstr, info).cuda()
+    W = _oracle_weight(oracle, qstr, info, m, k)
+    ref_mod = _RefStyleTCQ(layer)
+    ours_c = torch.compile(layer, fullgraph=True, backend="aot_eager")
+    ref_c = torch.compile(ref_mod, fullgraph=True, backend="aot_eager")
+    gen = torch.Generator().manual_seed(1)
+    for n in (1, 4, 12):
+        x = torch.randn(n, k, generator=gen).half()
+        y_e = layer(x.cuda().float())
+        y_o = ours_c(x.cuda().float())
+        y_r = ref_c(x.cuda().float())
+        assert torch.equal(y_e, y_o)
+        if n <= 8:
+            assert torch.equal(y_e, y_r)
+            _check_gemv(y_r.cpu().numpy(), W, x.numpy(), oracle)
+        else:  # the reference's bs > 8 path: decode + fp16 GEMM
+            ref = (x.float() @ torch.from_numpy(W).float().T).numpy()
+            assert np.allclose(y_r.cpu().numpy(), ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max())
+    # capture + replay of the compiled reference-style module
+    xs = torch.randn(1, k, generator=gen).half().cuda().float()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ref_c(xs)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            out = ref_c(xs)
+    xn = torch.randn(1, k, generator=gen).half()
+    xs.copy_(xn.cuda().float())
+    g.replay()
+    torch.cuda.synchronize()
+    _check_gemv(out.cpu().numpy(), W, xn.numpy(), oracle)
