@@ -217,3 +217,35 @@ print("ok")
 ''' % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_mi355x_latency_table_is_loadable_by_the_reference_solver():
+    """perf/latency/3_8b_latency_coeffs_mi355x.pt has the reference's format (solve_lat_const.py:113-123,
+    219-221: {f"{layer}_{quantizer_str}_{simt}": seconds} + a 0-d tensor 'constant') and its exact key set, so that the
+    fusion-aware solver can target MI355X; the solver's latency expression evaluates on the published figure1d result."""
+    import json
+    lat = torch.load(os.path.join(ROOT, "perf", "latency", "3_8b_latency_coeffs_mi355x.pt"), weights_only=True)
+    layers = ["q", "k", "v", "o", "u", "g", "d", "qk", "kv", "qv", "qkv", "ug"]
+    quants = ([f"tcq_{kv}_none_0.9" for kv in range(3, 11)] + [f"tcomb_{kv}_{kv + 1}_0.5_none_0.9" for kv in range(3, 10)] +
+              [f"ldlq_2_{b}_none_1.0" for b in range(3, 13)] + [f"ldlq_1_{b}_none_1.0" for b in range(2, 9)])
+    want = {f"{l}_{q}_False" for l in layers for q in quants} | {f"{l}_{q}_True" for l in layers for q in quants if q.startswith("ldlq")}
+    assert set(lat) == want | {"constant"} and len(lat) == 589  # the reference's assets/3_8b_latency_coeffs_4090_cc.pt: 589 keys
+    assert all(isinstance(lat[k], float) and 1e-6 < lat[k] < 1e-3 for k in want)
+    const = float(lat["constant"].item())                        # exactly how the solver reads it (l.114)
+    assert 0.0 < const < 0.05
+    with open(os.path.join(ROOT, "perf", "qdicts", "figure1d.json")) as f:
+        data = json.load(f)
+    short = {"self_attn.q_proj": "q", "self_attn.k_proj": "k", "self_attn.v_proj": "v", "self_attn.o_proj": "o",
+             "mlp.up_proj": "u", "mlp.gate_proj": "g", "mlp.down_proj": "d"}
+    total = const
+    for i, merges in enumerate(data["merge_info"]):
+        groups = [[k] for k in short]
+        for mg in merges:
+            members = [k for k in short if short[k] in mg.split("_")[1]]
+            groups = [g for g in groups if g[0] not in members] + [members]
+        for g in groups:
+            q, simt = data["qdict"][f"{i}_{g[0]}"]
+            key = "".join(short[k] for k in g)
+            key = {"gu": "ug", "ug": "ug"}.get(key, key)
+            total += lat[f"{key}_{q}_{'True' if simt == '1' else 'False'}"]
+    assert const < total < const + 0.01  # a decoded token of the published fusion-aware model, by the solver's formula
