@@ -75,6 +75,7 @@ def parse_args():
     ap.add_argument("--packing", default="qdict", choices=["qdict", "mi355x"],
                     help="qdict workloads: tensor-core-order vs SIMT packing of the VQ/SQ layers as published (chosen from the "
                          "reference's RTX 4090 latency table) or re-chosen from this GPU's table (perf/latency/)")
+    ap.add_argument("--no-kind-breakdown", action="store_true", help="skip the per-launch-kind timing of the default run")
     ap.add_argument("--no-incoherent-extra", action="store_true",
                     help="skip the second figure (token with the incoherence wrapper) of the default run")
     ap.add_argument("--no-fuse-rotation", action="store_true",
@@ -163,10 +164,16 @@ def build_model(qp, torch, model_key, qstr, nlayers, device, shard=None, distinc
     return layers
 
 
-def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=False, gather=None, side=(), main_stream=None):
+KINDS = ["q|k|v", "o", "gate|up", "down"]  # the four dependent multi-job launches of a decoder block
+
+
+def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=False, gather=None, side=(), main_stream=None,
+               only_kind=None):
     """-> (token, parts): token() runs every quantized linear of `layers` once (one decoded token at batch n, plain inputs
     xs[in_features]) and returns the outputs in model order; parts: the chain / multi-job partition of --launch chain, else
-    None.  Also what tests/test_bench_workloads.py drives for the published mixed-scheme workloads."""
+    None.  Also what tests/test_bench_workloads.py drives for the published mixed-scheme workloads.
+    only_kind (multi-job launches only): run just launch kind 0..3 of every block, with exactly the arguments it has inside
+    the token (timing of one launch kind; o / down then accumulate into whatever their pre-zeroed buffer holds)."""
     parts = None  # --launch chain: GemvChain objects (one launch each) and left-over Phases (multi-job launches)
     if launch == "chain" and gather is None:
         Phase = qp.chain.Phase
@@ -209,7 +216,10 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
                     nxt = gi + 1
                     if gi in (0, 2) and not no_prezero and len(groups[nxt]) == 1:
                         pre[nxt] = torch.empty((n, groups[nxt][0][0].out_features), dtype=torch.float32, device=device)
-                        outs += qp.multi_gemv(mods, x, prezero=pre[nxt])
+                        if only_kind is None or only_kind == gi:
+                            outs += qp.multi_gemv(mods, x, prezero=pre[nxt])
+                    elif only_kind is not None and only_kind != gi:
+                        pass
                     elif gi in pre:
                         outs += qp.multi_gemv(mods, x, outs=[pre[gi]], outs_zeroed=True)
                     else:
@@ -257,8 +267,11 @@ def algorithmic_bytes(qp, layers, batch):
 
 
 def cpu_baseline(qp, layers, batch, seconds):
-    """Time the CPU oracle (kind "port": fake-dequant to fp16 W, then fp32-accumulate x @ W.T, all host
-    cores via OpenMP) on ONE layer's 7 linears of the same workload, repeated within the time budget."""
+    """CPU baseline (kind "port": the oracle's restatement of what the reference does without a GPU — fake-dequant to fp16 W,
+    then fp32-accumulate x @ W.T; lib/quantizer/quant_op.py:185-201, lib/utils/kernel_decompress.py:64-88) on ONE layer's
+    linears of the same workload: all host cores (OpenMP) and one thread, W materialised and fused (decode a tile, multiply,
+    never write W).  All-core figures: median of >= 10 full-layer runs; one-thread figures: median of 3 runs of the layer's
+    smallest linear, scaled by weight count (a full layer on one thread takes ~20 s).  value = materialised, all cores."""
     import numpy as np
     from oracle import oracle
 
@@ -267,34 +280,58 @@ def cpu_baseline(qp, layers, batch, seconds):
     for mod, k, info in mods:
         m = mod.out_features
         x = np.random.default_rng(0).standard_normal((batch, k)).astype(np.float16)
-        host.append((info, m, k, x, np.empty((m, k), dtype=np.uint16)))
+        host.append(({kk: (v.cpu().numpy() if hasattr(v, "cpu") else v) for kk, v in info.items()}, m, k, x,
+                     np.empty((m, k), dtype=np.uint16)))
 
-    def one_layer():
-        for info, m, k, x, scratch in host:
-            if "trellis1" in info:
-                oracle.cpu_tcq_linear(info["trellis1"].cpu().numpy(), info["trellis2"].cpu().numpy(),
-                                      info["tlut"].cpu().numpy(), x, m, batch, k, info["tlut_bits"], info["KV"][0],
-                                      info["KV"][1], 2, scratch)
-            elif "trellis" in info:
-                oracle.cpu_tcq_linear(info["trellis"].cpu().numpy(), None, info["tlut"].cpu().numpy(), x, m, batch, k,
-                                      info["tlut_bits"], info["KV"], 0, 0, scratch)
-            else:
-                oracle.cpu_lut_tc_linear(info["qweight"].cpu().numpy(), info["lut"].cpu().numpy(), x, m, batch, k,
-                                         info["lut_bits"], info["vec_sz"], scratch)
+    def run_one(entry, fused):
+        info, m, k, x, scratch = entry
+        if "trellis1" in info:
+            args_ = (info["trellis1"], info["trellis2"], info["tlut"], x, m, batch, k, info["tlut_bits"], info["KV"][0], info["KV"][1], 2)
+            return oracle.cpu_tcq_linear_fused(*args_) if fused else oracle.cpu_tcq_linear(*args_, scratch)
+        if "trellis" in info:
+            args_ = (info["trellis"], None, info["tlut"], x, m, batch, k, info["tlut_bits"], info["KV"], 0, 0)
+            return oracle.cpu_tcq_linear_fused(*args_) if fused else oracle.cpu_tcq_linear(*args_, scratch)
+        args_ = (info["qweight"], info["lut"], x, m, batch, k, info["lut_bits"], info["vec_sz"])
+        return oracle.cpu_lut_tc_linear_fused(*args_) if fused else oracle.cpu_lut_tc_linear(*args_, scratch)
 
-    one_layer()  # warm-up (page faults, table init)
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        one_layer()
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or reps >= 50:
-            break
-    t_layer = el / reps
+    def timed(fn, reps):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), len(ts)
+
     nl = len(layers)
-    return {"value": 1.0 / (t_layer * nl), "unit": "tokens/s", "cores": oracle.num_threads(), "kind": "port",
-            "sample": f"1 of {nl} layers ({len(host)} linears, batch {batch}) x {reps} reps = {el:.1f} s; "
-                      f"per-token time extrapolated as {nl} x per-layer time"}
+    ncores = oracle.num_threads()
+    variants = {}
+    run_one(host[0], False)  # warm-up: page faults, table init
+    budget = max(2.0, seconds) / 3.0
+    for fused in (False, True):
+        def layer_run(f=fused):
+            for e in host:
+                run_one(e, f)
+        t1, _ = timed(layer_run, 1)
+        reps = max(10, min(50, int(budget / max(t1, 1e-3))))
+        t_layer, reps = timed(layer_run, reps)
+        variants[("fused" if fused else "materialise") + "_all_cores"] = {
+            "value": 1.0 / (t_layer * nl), "unit": "tokens/s", "cores": ncores, "median_layer_s": t_layer, "layer_runs": reps}
+    small = min(host, key=lambda e: e[1] * e[2])
+    frac = small[1] * small[2] / sum(e[1] * e[2] for e in host)
+    oracle.set_num_threads(1)
+    try:
+        for fused in (False, True):
+            t_small, reps = timed(lambda f=fused: run_one(small, f), 3)
+            variants[("fused" if fused else "materialise") + "_1_thread"] = {
+                "value": frac / (t_small * nl), "unit": "tokens/s", "cores": 1, "median_linear_s": t_small, "runs": reps,
+                "extrapolation": f"{small[1]}x{small[2]} linear = {frac:.4f} of a layer's weights"}
+    finally:
+        oracle.set_num_threads(ncores)
+    best = variants["materialise_all_cores"]
+    return {"value": best["value"], "unit": "tokens/s", "cores": ncores, "kind": "port",
+            "sample": f"1 of {nl} layers ({len(host)} linears, batch {batch}), median of {best['layer_runs']} full-layer runs; "
+                      f"per-token time = {nl} x per-layer time",
+            "variants": variants}
 
 
 def main():
@@ -437,6 +474,40 @@ def main():
         wall = time.perf_counter() - t0
         dev_s = e0.elapsed_time(e1) / 1e3
 
+    # Per launch kind (N = 1, multi-job launches, after the timed region): the four dependent launches of a block timed one
+    # kind at a time — 32 launches of that kind, each with its in-token arguments, as one graph — so that the launch
+    # furthest from the roofline can be read from the driver's record.
+    by_kind = None
+    if world == 1 and not args.incoherent and args.launch == "multi" and graph is not None and not args.no_kind_breakdown:
+        try:
+            by_kind = {}
+            with torch.cuda.stream(main_stream):
+                for gi, kname in enumerate(KINDS):
+                    ktoken, _ = make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=args.no_prezero,
+                                           only_kind=gi)
+                    ktoken()
+                    torch.cuda.synchronize()
+                    kg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(kg, stream=main_stream):
+                        ktoken()
+                    for _ in range(3):
+                        kg.replay()
+                    torch.cuda.synchronize()
+                    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    reps = max(5, min(args.steps, 50))
+                    k0.record(main_stream)
+                    for _ in range(reps):
+                        kg.replay()
+                    k1.record(main_stream)
+                    torch.cuda.synchronize()
+                    kbytes = algorithmic_bytes(qp, [[groups[gi]] for groups in layers], n)
+                    nk = sum(len(qp.linear.launch_groups([m for m, _, _ in groups[gi]], mixed_kv=n <= 8)) for groups in layers)
+                    t_k = k0.elapsed_time(k1) / 1e3 / reps
+                    by_kind[kname] = {"launches": nk, "bytes_per_launch": kbytes / nk, "us_per_launch": t_k / nk * 1e6,
+                                      "achieved_GBps": kbytes / t_k / 1e9, "frac": kbytes / t_k / 1e9 / HBM_PEAK_GBS}
+        except Exception as exc:  # the headline line must not depend on this leg
+            by_kind = {"error": repr(exc)}
+
     # Second figure (N = 1 only, after the timed region of the headline): the same token with every projection group
     # inside the reference's incoherence wrapper (rotation + scales), i.e. what an IncoherentMLP / attention forward costs.
     extra = None
@@ -501,12 +572,15 @@ def main():
                    "rotation_launches_per_token": (nlayers + nrot[0]) if args.incoherent else 0},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
+                     "traffic_source": traffic_source(),
                      "kernel": ("qpal::tc_chain_kernel (persistent: every GEMV phase of a token)" if parts is not None
                                 else "qpal::tc_gemv_kernel (every GEMV launch of a token)"),
                      "algorithmic_bytes_per_launch": abytes / (world if tp else 1) / nlaunch,
                      "avg_launch_us": t_token / nlaunch * 1e6,
                      "avg_phase_us": t_token / nphase * 1e6},
     }
+    if by_kind is not None:
+        out["roofline"]["by_launch_kind"] = by_kind
     if extra is not None:
         out["with_incoherence_wrapper"] = extra
     if rank == 0:
@@ -518,11 +592,21 @@ def main():
 
 
 def load_traffic(workload):
-    """HBM bytes per launch from the rocprofv3 PMC pass committed under profiles/ (None if absent)."""
+    """HBM bytes per launch from the rocprofv3 PMC pass committed under profiles/ (None if absent).  NOT measured by this run:
+    the JSON line names the file it was read from (roofline.traffic_source)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             return json.load(f).get(workload)
+    except (OSError, ValueError):
+        return None
+
+
+def traffic_source():
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("_source", "profiles/traffic.json (committed rocprofv3 --pmc FETCH_SIZE pass; not measured by this run)")
     except (OSError, ValueError):
         return None
 

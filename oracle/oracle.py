@@ -159,3 +159,21 @@ def cpu_lut_tc_linear(qweight, lut, x, m, n, k, bits, vec, scratch=None):
     out = np.empty((n, m), dtype=np.float32)
     lib().qo_cpu_lut_tc_linear(_p(q), _p(l), _p(xx), m, n, k, bits, vec, _p(scratch), _p(out))
     return out
+
+
+def cpu_tcq_linear_fused(c1, c2, tlut, x, m, n, k, S, KV1, KV2, split):
+    """Fused CPU variant: decode tile by tile and multiply at once, W is never written (bench.py cpu_baseline, tests)."""
+    c1 = _u16(c1)
+    c2a = _u16(c2) if c2 is not None else c1
+    out = np.empty((n, m), dtype=np.float32)
+    rc = lib().qo_cpu_tcq_linear_fused(_p(c1), _p(c2a), _p(_u16(tlut)), _p(_u16(x)), m, n, k, S, KV1, KV2, split, _p(out))
+    assert rc == 0
+    return out
+
+
+def cpu_lut_tc_linear_fused(qweight, lut, x, m, n, k, bits, vec):
+    out = np.empty((n, m), dtype=np.float32)
+    rc = lib().qo_cpu_lut_tc_linear_fused(_p(_u32(qweight)), _p(_u16(lut)), _p(_u16(x)), m, n, k, bits, vec, _p(out))
+    assert rc == 0
+    return out
+

@@ -323,3 +323,88 @@ int qo_cpu_lut_tc_linear(const uint32_t *qweight, const uint16_t *lut, const uin
     gemv_f32acc(Wscratch, x, m, n, k, out);
     return 0;
 }
+
+/* ------------------------------------------------------------------ CPU baseline, fused variant */
+/* The same arithmetic without ever writing W: every 16x16 tile is decoded into registers / L1 and multiplied at once
+ * ("plus a fused no-materialise variant").  fp32 accumulation per (batch, row), tile by tile along K.  */
+static void tcq_fused_block(const uint16_t *trellis, const uint16_t *tlut, int m, int k, int S, int KV, const uint16_t *x,
+                            int n, int ldx, int col0, float *out, int ldo, int row0, int accumulate) {
+    const uint8_t *bytes = (const uint8_t *)trellis;
+    int ntc = k / 16;
+    ensure_h2f();
+#pragma omp parallel for schedule(static)
+    for (int tr = 0; tr < m / 16; tr++) {
+        uint16_t st[128];
+        float acc[8][16];
+        for (int b = 0; b < n; b++)
+            for (int r = 0; r < 16; r++) acc[b][r] = 0.f;
+        for (int tc = 0; tc < ntc; tc++) {
+            tcq_tile_states(bytes, k, KV, tr, tc, st);
+            for (int r = 0; r < 16; r++)
+                for (int c = 0; c < 16; c += 2) {
+                    uint16_t w0, w1;
+                    tcq_state_to_pair(st[tile_seq_pos(r, c) >> 1], tlut, S, &w0, &w1);
+                    float f0 = h2f_table[w0], f1 = h2f_table[w1];
+                    for (int b = 0; b < n; b++) {
+                        const uint16_t *xx = x + (size_t)b * ldx + col0 + tc * 16 + c;
+                        acc[b][r] += f0 * h2f_table[xx[0]] + f1 * h2f_table[xx[1]];
+                    }
+                }
+        }
+        for (int b = 0; b < n; b++)
+            for (int r = 0; r < 16; r++) {
+                float *dst = out + (size_t)b * ldo + row0 + tr * 16 + r;
+                *dst = accumulate ? *dst + acc[b][r] : acc[b][r];
+            }
+    }
+}
+
+int qo_cpu_tcq_linear_fused(const uint16_t *c1, const uint16_t *c2, const uint16_t *tlut, const uint16_t *x, int m, int n,
+                            int k, int S, int KV1, int KV2, int split, float *out) {
+    if (n < 1 || n > 8) return -1;
+    if (split == 0) {
+        tcq_fused_block(c1, tlut, m, k, S, KV1, x, n, k, 0, out, m, 0, 0);
+    } else if (split == 1) {
+        tcq_fused_block(c1, tlut, m / 2, k, S, KV1, x, n, k, 0, out, m, 0, 0);
+        tcq_fused_block(c2, tlut, m / 2, k, S, KV2, x, n, k, 0, out, m, m / 2, 0);
+    } else if (split == 2) {
+        tcq_fused_block(c1, tlut, m, k / 2, S, KV1, x, n, k, 0, out, m, 0, 0);
+        tcq_fused_block(c2, tlut, m, k / 2, S, KV2, x, n, k, k / 2, out, m, 0, 1);
+    } else {
+        return -1;
+    }
+    return 0;
+}
+
+int qo_cpu_lut_tc_linear_fused(const uint32_t *qweight, const uint16_t *lut, const uint16_t *x, int m, int n, int k,
+                               int bits, int vec, float *out) {
+    const uint8_t *bytes = (const uint8_t *)qweight;
+    int ncode = 8 / vec, gbits = ncode * bits;
+    if (n < 1 || n > 8) return -1;
+    ensure_h2f();
+#pragma omp parallel for schedule(static)
+    for (int tr = 0; tr < m / 16; tr++) {
+        float acc[8][16];
+        for (int b = 0; b < n; b++)
+            for (int r = 0; r < 16; r++) acc[b][r] = 0.f;
+        for (int tc = 0; tc < k / 16; tc++) {
+            int sr = tr >> 1, msub = tr & 1, sc = tc >> 1, ksub = tc & 1;
+            for (int lane = 0; lane < 32; lane++) {
+                uint64_t base = ((((uint64_t)sr * (k / 32) + sc) * 32 + lane) * 4 + (uint64_t)(ksub * 2 + msub)) * gbits;
+                for (int q = 0; q < ncode; q++) {
+                    int32_t code = (int32_t)le_bits(bytes, base + (uint64_t)q * bits, bits);
+                    int j = (vec == 1) ? (q >> 1) : q, e = (vec == 1) ? (q & 1) : 0;
+                    int r = (lane >> 2) + 8 * (j & 1), c = 2 * (lane & 3) + 8 * (j >> 1) + e;
+                    for (int v = 0; v < vec; v++) {
+                        float w = h2f_table[lut[(size_t)code * vec + v]];
+                        for (int b = 0; b < n; b++) acc[b][r] += w * h2f_table[x[(size_t)b * k + tc * 16 + c + v]];
+                    }
+                }
+            }
+        }
+        for (int b = 0; b < n; b++)
+            for (int r = 0; r < 16; r++) out[(size_t)b * m + tr * 16 + r] = acc[b][r];
+    }
+    return 0;
+}
+
