@@ -209,6 +209,12 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
             for gi, grp in enumerate(groups):
                 x = xs[grp[0][1]]
                 mods = [m for m, _, _ in grp]
+                if n > min(m.max_fused_batch for m in mods) and gather is None:
+                    # beyond the fused batch: decode to fp16 W (staged 16-byte stores) + fp16 GEMM, as the reference does for
+                    # bs > 8 (lib/linear/tcq_linear.py:75-84); the MFMA roofline of this path is reported by --batch
+                    if only_kind is None or only_kind == gi:
+                        outs += [m(x) for m in mods]
+                    continue
                 if launch in ("multi", "chain") and gather is None:
                     # projections of one input: one multi-job launch per codec.  The attention-input / mlp-input
                     # launches also zero the output of o_proj / down_proj, so that a split-K there (few rows:
@@ -581,6 +587,12 @@ def main():
     }
     if by_kind is not None:
         out["roofline"]["by_launch_kind"] = by_kind
+    if n > 8:  # skinny GEMM / decode + fp16 GEMM: a dense contraction, priced against the matrix pipe as well
+        flops = 2.0 * n * sum(m.out_features * k for groups in layers for grp in groups for m, k, _ in grp)
+        out["roofline_mfma"] = {"bound": "mfma", "achieved": flops / t_token / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                                "frac": flops / t_token / 1e12 / 2500.0,
+                                "note": "batch <= 64: fused decode + MFMA skinny GEMM (one decode feeds every batch group); above: decode "
+                                        "to fp16 W in HBM (staged 16-byte stores) + fp16 GEMM (hipBLASLt)"}
     if extra is not None:
         out["with_incoherence_wrapper"] = extra
     if rank == 0:

@@ -11,8 +11,10 @@ int launch_lut_tc_gemv(const TcMultiParams &p, int bits, int vec, int nbg, int g
     if (bits == B_ && vec == V_) {                                                                             \
         if (nbg == 1)                                                                                          \
             hipLaunchKernelGGL((tc_gemv_kernel<LutCodec<B_, V_>, void, 1>), dim3(grid), dim3(1024), 0, stream, e.x, e.tab, e.n, e.k, e.on, p); \
-        else                                                                                                   \
+        else if (nbg == 2)                                                                                     \
             hipLaunchKernelGGL((tc_gemv_kernel<LutCodec<B_, V_>, void, 2>), dim3(grid), dim3(1024), 0, stream, e.x, e.tab, e.n, e.k, e.on, p); \
+        else                                                                                                   \
+            return launch_lut_tc_gemv_wide(p, bits, vec, nbg, grid, stream);                                   \
         return (int)hipGetLastError();                                                                         \
     }
 #include "lut_table.inc"

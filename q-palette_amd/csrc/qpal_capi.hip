@@ -13,7 +13,11 @@ using namespace qpal;
 
 namespace {
 
-constexpr int kMaxBatch = 16;  // fused decode + GEMV / skinny GEMM: 2 MFMA column groups of 8 batch rows
+constexpr int kMaxBatch = 64;  // fused decode + GEMV / skinny GEMM: up to 8 MFMA column groups of 8 batch rows
+
+// MFMA column groups for a batch: 1, 2 (16 waves per workgroup), 4, 8 (8 waves: tc_kernels.h gemv_waves)
+int nbg_of(int n) { return n <= 8 ? 1 : n <= 16 ? 2 : n <= 32 ? 4 : 8; }
+int waves_of(int nbg) { return nbg >= 4 ? 8 : 16; }
 
 inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
@@ -106,7 +110,7 @@ int items_at(const TcMultiParams &mp, int log2_wpr, int waves = 16) {
 }
 
 // out_zeroed[j]: the caller pre-zeroed job j's output (split-K is then free of a memset node)
-void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid) {
+void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves = 16) {
     static const int force_sk = env_int("QPAL_FORCE_SK", 0);
     static const int force_wpr = env_int("QPAL_FORCE_WPR", -1);
     int min_st = 1 << 30;
@@ -116,24 +120,25 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid) {
         if (st < min_st) min_st = st;
         two = two || mp.job[j].st2 > 0;
     }
-    int log2_wpr = 4;
-    while (log2_wpr > 0 && items_at(mp, log2_wpr) > kNumCU) log2_wpr--;
+    const int log2w = waves == 16 ? 4 : 3;
+    int log2_wpr = log2w;
+    while (log2_wpr > 0 && items_at(mp, log2_wpr, waves) > kNumCU) log2_wpr--;
     while (log2_wpr > 0 && (1 << log2_wpr) > min_st) log2_wpr--;   // no more waves per row than steps
     if (two && log2_wpr == 0) log2_wpr = 1;                         // a combt row needs >= 2 chunks
-    if (force_wpr >= 0) log2_wpr = force_wpr;
-    const int items = items_at(mp, log2_wpr);
+    if (force_wpr >= 0 && force_wpr <= log2w) log2_wpr = force_wpr;
+    const int items = items_at(mp, log2_wpr, waves);
     for (int j = 0; j < mp.njobs; j++) {
         TcParams &p = mp.job[j];
         int sk = 1;
         const int per_wave = (p.st1 + p.st2 + (1 << log2_wpr) - 1) >> log2_wpr;
-        if (items * 2 <= kNumCU && log2_wpr == 4) {
+        if (items * 2 <= kNumCU && log2_wpr == log2w) {
             // idle CUs: share each row's K range between workgroups if the waves have steps to give away
             const int want = kNumCU / items;
             const int min_steps = (out_zeroed && out_zeroed[j]) ? 2 : 6;  // a memset node costs ~3 us
             while (sk * 2 <= want && per_wave / (sk * 2) * 2 >= min_steps) sk *= 2;
         }
         if (force_sk > 0) sk = force_sk;
-        set_chunks(p, log2_wpr, sk);
+        set_chunks(p, log2_wpr, sk, waves);
     }
     int total = 0;
     for (int j = 0; j < kMaxJobs; j++) {
@@ -219,6 +224,16 @@ void tcq_fill(TcParams &p, float *out, long ldo, const void *c1, const void *c2,
     p.x_lds = x_fits_lds(n, k);
 }
 
+// Decode-to-fp16 work items: supertile rows cut into column chunks until there are >= 8 items per CU (a row-only grid left
+// half of the chip idle for m = 4096 and 12 % at m = 14336); every wave still needs a step of its own: chunk >= 16 steps
+int dequant_chunks(int nrows, int st1, int st2) {
+    int st = st1;
+    if (st2 > 0 && st2 < st) st = st2;
+    int nch = 1;
+    while (nrows * nch < 8 * kNumCU && st / (nch * 2) >= 16) nch *= 2;
+    return nch;
+}
+
 int zero_if_split(const TcParams &p, int m, hipStream_t stream, int out_zeroed = 0) {
     if (p.sk > 1 && !out_zeroed) {
         for (int b = 0; b < p.n; b++) {
@@ -235,10 +250,11 @@ int tcq_gemv_one(float *out, long ldo, const void *c1, const void *c2, const voi
     mp.njobs = 1;
     tcq_fill(mp.job[0], out, ldo, c1, c2, x, tlut, m, n, k, k1, k2);
     int grid;
-    plan_launch(mp, nullptr, grid);
+    const int nbg = nbg_of(n);
+    plan_launch(mp, nullptr, grid, waves_of(nbg));
     int rc = zero_if_split(mp.job[0], m, stream);
     if (rc) return rc;
-    return launch_tcq_gemv(mp, S, KV1, KV2, n <= 8 ? 1 : 2, grid, stream);
+    return launch_tcq_gemv(mp, S, KV1, KV2, nbg, grid, stream);
 }
 
 int tcq_check(const void *c1, const void *c2, const void *tlut, int m, int k, int S, int KV1, int KV2, int split) {
@@ -326,13 +342,17 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
     mp.zero = static_cast<u32x4 *>(prezero);
     mp.zero_chunks = (int)(prezero_bytes / 16);
     int grid;
-    plan_launch(mp, zeroed, grid);
+    const int nbg = nbg_of(n);
+    if (nbg >= 4)
+        for (int j = 0; j < njobs; j++)
+            if (jobs[j].x_had) return QPAL_E_SHAPE;  // fused rotation: batch 1
+    plan_launch(mp, zeroed, grid, waves_of(nbg));
     for (int j = 0; j < njobs; j++) {
         int rc = zero_if_split(mp.job[j], jobs[j].m, s, jobs[j].out_zeroed);
         if (rc) return rc;
     }
     if (mixed) return launch_tcq_gemv_any(mp, S, grid, s);
-    return launch_tcq_gemv(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, n <= 8 ? 1 : 2, grid, s);
+    return launch_tcq_gemv(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, nbg, grid, s);
 }
 
 int qpal_tcq_dequant(void *out_f16, const void *c1, const void *c2, const void *tlut, int m, int k, int S, int KV1,
@@ -355,7 +375,10 @@ int qpal_tcq_dequant(void *out_f16, const void *c1, const void *c2, const void *
         p.st1 = (p.nsc1 + 3) / 4;
         p.st2 = (p.nsc2 + 3) / 4;
         p.col2 = k1;
-        const int grid = p.nrows < kNumCU ? p.nrows : kNumCU;
+        p.x_lds = aligned(w, 16) && (k % 8) == 0 && (k1 % 8) == 0 && !getenv("QPAL_DEQUANT_DIRECT");  // staged 16-byte stores
+        p.sk = dequant_chunks(p.nrows, p.st1, p.st2);
+        const int items = p.x_lds ? p.nrows * p.sk : p.nrows;
+        const int grid = items < kNumCU ? items : kNumCU;
         return launch_tcq_dequant(p, S, kva, kvb, grid, s);
     };
     uint16_t *w = static_cast<uint16_t *>(out_f16);
@@ -428,12 +451,15 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
     mp.zero = static_cast<u32x4 *>(prezero);
     mp.zero_chunks = (int)(prezero_bytes / 16);
     int grid;
-    plan_launch(mp, zeroed, grid);
+    const int nbg = nbg_of(n);
+    // the reduction buffer of 8 batch groups (64 KiB) does not fit beside a 128 KiB codebook image
+    if (nbg == 8 && lut_image_bytes(bits, vec) > 64 * 1024) return QPAL_E_SHAPE;
+    plan_launch(mp, zeroed, grid, waves_of(nbg));
     for (int j = 0; j < njobs; j++) {
         int rc = zero_if_split(mp.job[j], jobs[j].m, s, jobs[j].out_zeroed);
         if (rc) return rc;
     }
-    return launch_lut_tc_gemv(mp, bits, vec, n <= 8 ? 1 : 2, grid, s);
+    return launch_lut_tc_gemv(mp, bits, vec, nbg, grid, s);
 }
 
 int qpal_lut_tc_dequant(void *out_f16, const void *qweight, const void *lut, int m, int k, int bits, int vec,
@@ -450,7 +476,10 @@ int qpal_lut_tc_dequant(void *out_f16, const void *qweight, const void *lut, int
     p.nrows = m / 32;
     p.nsc1 = k / 32;
     p.st1 = (p.nsc1 + 3) / 4;
-    const int grid = p.nrows < kNumCU ? p.nrows : kNumCU;
+    p.x_lds = aligned(out_f16, 16) && (k % 8) == 0 && !getenv("QPAL_DEQUANT_DIRECT");  // staged 16-byte stores
+    p.sk = dequant_chunks(p.nrows, p.st1, 0);
+    const int items = p.x_lds ? p.nrows * p.sk : p.nrows;
+    const int grid = items < kNumCU ? items : kNumCU;
     return launch_lut_tc_dequant(p, bits, vec, grid, static_cast<hipStream_t>(stream));
 }
 
@@ -612,7 +641,7 @@ int qpal_can_fuse_rotation(int n, int k) { return n >= 1 && k > 0 && rot_ok(n, k
 const char *qpal_error_string(int code) {
     switch (code) {
         case QPAL_OK: return "ok";
-        case QPAL_E_SHAPE: return "unsupported shape (need m%32==0, k%32==0, 1<=n<=16; see include/qpal.h)";
+        case QPAL_E_SHAPE: return "unsupported shape (need m%32==0, k%32==0, 1<=n<=64; see include/qpal.h)";
         case QPAL_E_PARAM: return "unsupported quantizer parameters (S/KV/bits/vec/split)";
         case QPAL_E_NULL: return "null pointer";
         case QPAL_E_ALIGN: return "misaligned pointer";

@@ -371,9 +371,13 @@ __device__ __forceinline__ void gemv_run(uint32_t (&w)[Codec::NW], const uint32_
     }
 }
 
-// LDS beside the 64 KiB codebook image: reduction buffer [16 waves][n][32] fp32 (+ x for batch <= 8)
+// Waves per workgroup of the fused kernel: 16 (4 per SIMD, 128 VGPRs) up to batch 16; 8 (2 per SIMD, 256 VGPRs: room for
+// the accumulators and activations of 4 / 8 batch groups) for batches 17..64, where every decoded step feeds 32 / 64 MFMAs
 template <int NBG>
-constexpr int scratch_bytes() { return NBG == 1 ? kScratchBytes : 16 * 32 * 4 * 8 * NBG; }
+constexpr int gemv_waves() { return NBG >= 4 ? 8 : 16; }
+// LDS beside the 64 KiB codebook image: reduction buffer [waves][n][32] fp32 (+ x for batch <= 8)
+template <int NBG>
+constexpr int scratch_bytes() { return NBG == 1 ? kScratchBytes : gemv_waves<NBG>() * 32 * 4 * 8 * NBG; }
 
 // Mixed-precision launches: everything about a TCQ codec except the bit surgery depends on the codebook size S only (the
 // LDS image, its address mask, the hash), so single-stream layers of one S but DIFFERENT KV — q, k and v of a mixed-scheme
@@ -428,10 +432,12 @@ inline TcEarly early_args(const TcMultiParams &mp) {
 }
 
 template <class C1, class C2, int NBG, bool ROT = false>
-__global__ __launch_bounds__(1024) void tc_gemv_kernel(const uint16_t *ex, const void *etab, int en, int ek, int eon,
+__global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const uint16_t *ex, const void *etab, int en, int ek, int eon,
                                                        const TcMultiParams mp) {
     constexpr bool TWO = !std::is_void_v<C2>;
     using CB = std::conditional_t<TWO, C2, C1>;
+    constexpr int W = gemv_waves<NBG>(), LOG2W = W == 16 ? 4 : 3, NT = 64 * W;
+    static_assert(!ROT || NBG == 1, "fused rotation: batch 1 kernels");
     __shared__ __attribute__((aligned(16))) uint32_t lut[C1::LDS_DWORDS];
     __shared__ __attribute__((aligned(16))) unsigned char scratch[scratch_bytes<NBG>()];
 
@@ -494,12 +500,12 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const uint16_t *ex, const
             cur_j = j;
         }
         const int item = gitem - item_begin;
-        float *red = reinterpret_cast<float *>(scratch);                           // [16][n][32]
-        uint16_t *xs = reinterpret_cast<uint16_t *>(scratch + 16 * 32 * 4 * p.n);  // [n][k] + 32 zero halves
+        float *red = reinterpret_cast<float *>(scratch);                           // [W][n][32]
+        uint16_t *xs = reinterpret_cast<uint16_t *>(scratch + W * 32 * 4 * p.n);   // [n][k] + 32 zero halves
         const int wpr = 1 << p.log2_wpr;
         const int rloc = wave >> p.log2_wpr;  // supertile row inside the workgroup's row group
         const int wr = wave & (wpr - 1);      // this wave's K-chunk inside the row
-        const int log2_rpw = 4 - p.log2_wpr;  // log2(rows per workgroup)
+        const int log2_rpw = LOG2W - p.log2_wpr;  // log2(rows per workgroup)
         const int zero_off = p.n * p.k;
         const bool x_lds = NBG == 1 && p.x_lds;
         QPAL_STAMP(0);
@@ -567,7 +573,7 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const uint16_t *ex, const
             }
         }
         if (gitem == (int)blockIdx.x && mp.zero_chunks > 0) {  // pre-zero a buffer for a later split-K launch on this stream
-            for (int i = blockIdx.x * 1024 + tid; i < mp.zero_chunks; i += gridDim.x * 1024) mp.zero[i] = u32x4{0u, 0u, 0u, 0u};
+            for (int i = blockIdx.x * NT + tid; i < mp.zero_chunks; i += gridDim.x * NT) mp.zero[i] = u32x4{0u, 0u, 0u, 0u};
         }
         QPAL_STAMP(1);
         if (p.tab != cur_tab || (x_lds && p.x != cur_x)) {  // workgroup-uniform
@@ -607,7 +613,7 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const uint16_t *ex, const
                     else wht64_wg_stage2<2>(wave, lane, p.x_pre, d1buf, store_row(xs));
                   }
                 } else {
-                    for (int i = tid * 8; i < total + 32; i += 1024 * 8) {
+                    for (int i = tid * 8; i < total + 32; i += NT * 8) {
                         u32x4 v{0u, 0u, 0u, 0u};
                         if (i < total) v = *reinterpret_cast<const u32x4 *>(p.x + i);
                         *reinterpret_cast<u32x4 *>(xs + i) = v;
@@ -616,7 +622,7 @@ __global__ __launch_bounds__(1024) void tc_gemv_kernel(const uint16_t *ex, const
                 cur_x = p.x;
             }
             if (p.tab != cur_tab) {
-                C1::build(lut, p.tab, tid, 1024);
+                C1::build(lut, p.tab, tid, NT);
                 cur_tab = p.tab;
             }
             QPAL_STAMP(2);
@@ -732,6 +738,58 @@ __device__ __forceinline__ void dequant_stream(const uint32_t *lut, uint32_t lan
     }
 }
 
+// Staged form of the same step: the wave's 32 x 128 tile goes through a private LDS buffer (16 rows x 256 B + 16 B pad, one
+// msub half at a time) and leaves as 16-byte stores that cover whole 256-byte row segments — four full 128-byte lines per
+// row and instruction instead of 16-byte runs in 32 different rows (the direct form above: 2.1-2.8 TB/s written).
+constexpr int kDqStageRowHalves = 136;                       // 272 bytes: conflict-free ds_write_b64 / ds_read_b128
+constexpr int kDqStageBytes = 16 * kDqStageRowHalves * 2;    // per wave
+template <class Codec>
+__device__ __forceinline__ void dequant_step_staged(const uint32_t *lut, uint32_t laneoff, const uint32_t (&w)[Codec::NW],
+                                                    uint16_t *stage, uint16_t *__restrict__ wtile, long ldw, int lane,
+                                                    int cols_valid) {
+    // wtile -> W[32*sr][col0 + 128*step]; cols_valid: live columns of this step (multiple of 32, <= 128)
+    const int p = lane & 15, sc = lane >> 4, u = p & 1;
+    static_for<0, 2>([&](auto mc) {
+        constexpr int msub = decltype(mc)::value;
+        static_for<0, 2>([&](auto kc) {
+            constexpr int ksub = decltype(kc)::value;
+            constexpr int g = ksub * 2 + msub;
+            uint32_t nh = 0u;
+            if constexpr (Codec::kNeedsNext) nh = row16_next(Codec::template head<g>(w));
+            static_for<0, 4>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int jl = j & 1, jh = j >> 1;
+                const uint32_t va = Codec::template pair<g, j>(lut, laneoff, w, nh);
+                const uint32_t vb = Codec::template pair<g, j + 4>(lut, laneoff, w, nh);
+                uint16_t *dst = stage + (8 * jl + (p >> 1)) * kDqStageRowHalves + 32 * sc + 16 * ksub + 8 * jh + 4 * u;
+                *reinterpret_cast<u32x2 *>(dst) = u32x2{va, vb};
+            });
+        });
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = (lane >> 4) + 4 * i, col = 8 * (lane & 15);
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(stage + row * kDqStageRowHalves + col);
+            if (col < cols_valid) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(wtile + (long)(16 * msub + row) * ldw + col));
+        }
+    });
+}
+
+template <class Codec>
+__device__ __forceinline__ void dequant_stream_staged(const uint32_t *lut, uint32_t laneoff, const uint32_t *__restrict__ c,
+                                                      int nsc, int nst, int col0, uint16_t *__restrict__ wout, long ldw,
+                                                      int sr, int wave, int lane, uint16_t *stage, int ch, int nch) {
+    constexpr int NW = Codec::NW;
+    const StreamView sv{c + (long)sr * nsc * 16 * NW, nsc, col0};
+    const int s_lo = (int)((long)nst * ch / nch), s_hi = (int)((long)nst * (ch + 1) / nch);  // this workgroup's share of the row
+    for (int s = s_lo + wave; s < s_hi; s += 16) {
+        uint32_t w[NW];
+        load_step_w<NW>(sv, s, lane, w);
+        int valid = (nsc - 4 * s) * 32;
+        valid = valid > 128 ? 128 : valid;
+        dequant_step_staged<Codec>(lut, laneoff, w, stage, wout + (long)sr * 32 * ldw + col0 + (long)s * 128, ldw, lane, valid);
+    }
+}
+
 template <class C1, class C2>
 __global__ __launch_bounds__(1024) void tc_dequant_kernel(const TcParams p) {
     __shared__ __attribute__((aligned(16))) uint32_t lut[C1::LDS_DWORDS];
@@ -740,6 +798,23 @@ __global__ __launch_bounds__(1024) void tc_dequant_kernel(const TcParams p) {
     const uint32_t laneoff = (uint32_t)(lane & (C1::C - 1)) << 2;
     C1::build(lut, p.tab, tid, 1024);
     __syncthreads();
+    // 16-byte row-segment stores through a per-wave LDS transpose where the buffers fit beside the image (64 KiB images)
+    // and the output allows 16-byte stores; the direct 8-byte form otherwise
+    constexpr bool kStage = C1::LDS_DWORDS * 4 + 16 * kDqStageBytes <= 160 * 1024;
+    if constexpr (kStage) {
+        __shared__ __attribute__((aligned(16))) uint16_t stage_all[16 * kDqStageBytes / 2];
+        if (p.x_lds) {  // host: wout and ldw are 16-byte friendly
+            uint16_t *stage = stage_all + wave * (kDqStageBytes / 2);
+            const int nch = p.sk < 1 ? 1 : p.sk;  // column chunks per supertile row: enough items to balance the CUs
+            for (int item = blockIdx.x; item < p.nrows * nch; item += gridDim.x) {
+                const int sr = item / nch, ch = item - sr * nch;
+                dequant_stream_staged<C1>(lut, laneoff, p.c1, p.nsc1, p.st1, 0, p.wout, p.ldw, sr, wave, lane, stage, ch, nch);
+                if constexpr (!std::is_void_v<C2>)
+                    dequant_stream_staged<C2>(lut, laneoff, p.c2, p.nsc2, p.st2, p.col2, p.wout, p.ldw, sr, wave, lane, stage, ch, nch);
+            }
+            return;
+        }
+    }
     for (int sr = blockIdx.x; sr < p.nrows; sr += gridDim.x) {
         dequant_stream<C1>(lut, laneoff, p.c1, p.nsc1, p.st1, 0, p.wout, p.ldw, sr, wave, lane);
         if constexpr (!std::is_void_v<C2>)

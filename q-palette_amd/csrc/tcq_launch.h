@@ -47,7 +47,7 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
         hipFree(d);
     }
 #endif
-    hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(1024), 0, stream, e.x, e.tab, e.n, e.k, e.on, mp);
+    hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(64 * gemv_waves<NBG>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, mp);
     return (int)hipGetLastError();
 }
 

@@ -109,9 +109,9 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
 
     x2 = x.reshape(-1, layers[0].in_features)
     n = x2.shape[0]
-    if n > 16:  # decode-to-fp16 + GEMM path of the modules: the fused-launch extras have no meaning there
+    if n > min(l.max_fused_batch for l in layers):  # decode-to-fp16 + GEMM path of the modules: the fused-launch extras have no meaning there
         if outs is not None or prezero is not None or wscales is not None or oscale != 1.0 or x_rot is not None:
-            raise RuntimeError("multi_gemv: outs / prezero / wscales / oscale / x_rot need a fused batch (n <= 16)")
+            raise RuntimeError("multi_gemv: outs / prezero / wscales / oscale / x_rot need a fused batch (n <= 64)")
         return [l(x2) for l in layers]
     results = [None] * len(layers)
     mixed_kv = x_rot is None and n <= 8  # the any-KV kernel has no rotation / batch > 8 variants

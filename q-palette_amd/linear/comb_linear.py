@@ -13,7 +13,7 @@ def _trellis_buffer(rows, cols, KV, td_x=16, td_y=16, V=2):
 
 
 class _CombBase(PackedLinearBase):
-    max_fused_batch = 16
+    max_fused_batch = 64  # batches 17..64: 4 / 8 MFMA column groups per decoded step (512-thread workgroups)
     part_key = None
 
     def _common_init(self, in_features, out_features, td_x, td_y, part, L, KV, V, tlut_bits, bias, dtype):

@@ -42,11 +42,15 @@ class _VQBase(PackedLinearBase):
 
 class VQLinearPackTensorCore(_VQBase):
     """Codes stored in mma-tile order (quant_op.py:101-162); fp32 GEMV output."""
-    max_fused_batch = 16
+    max_fused_batch = 64
 
     def __init__(self, in_features, out_features, lut_bits, vec_sz=2, bias=False, dtype=torch.half, device=None):
         super().__init__(in_features, out_features, lut_bits, vec_sz, bias, dtype, device)
         self.vq_type = f"vq{vec_sz}" if vec_sz > 1 else ("sq_dup" if lut_bits <= 4 else "sq")
+        # the reduction buffer of 8 batch groups does not fit beside a 128 KiB codebook image (csrc/qpal_capi.hip)
+        idx = lut_bits if vec_sz == 2 else (2 * lut_bits if lut_bits <= 6 else lut_bits)
+        if (4 << (idx + min(15 - idx, 5))) > 64 * 1024:
+            self.max_fused_batch = 32
         self.register_ops()
 
     def op_names(self):

@@ -16,7 +16,7 @@ Name grammar (reference file:line):
   decompress_{bits}_{vtype}                                     :94-117
   sq_pack_gemm_simt / sq_pack_dequant_simt / sq_pack_gemm_inplace_simt   :349-378
   vq_pack_gemm_simt_{maxm}_{vec}_{bits} ; vq_pack_dequant_simt_{vec}_{bits}   :383-420
-Unlike the reference, any 1 <= n <= 16 (tensor-core-order families; SIMT: n <= 8) and any m % 32 == 0,
+Unlike the reference, any 1 <= n <= 64 (tensor-core-order families; SIMT: n <= 8) and any m % 32 == 0,
 k % 32 == 0 is accepted at run time.
 """
 import re
@@ -285,7 +285,7 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
     wscales / oscale: fused epilogue out = acc * wscales[j][row] * oscale (the incoherent wrappers' Wscale * scale).
     x_rot = (su, post): x is the un-rotated input; the kernel stages fp16(fp16(H (x * su) / sqrt(k)) * post) itself."""
     n, k = x.shape
-    _chk(1 <= n <= MAX_FUSED_BATCH, "batch size must be in 1..16")
+    _chk(1 <= n <= MAX_FUSED_BATCH, "batch size must be in 1..64")
     xh = _dev(x.to(torch.float16), "x")
     had, xpost, xsu = _rot_args(x_rot, xh, k)
     jobs = (nat.TcqJob * len(streams))()
@@ -320,7 +320,7 @@ def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezer
     """Several VQ/SQ (tensor-core packing) GEMVs of one codec and one input in ONE launch.
     layers: list of (qweight, lut, m); x: [n, k].  outs / outs_zeroed / prezero as in tcq_gemv_multi."""
     n, k = x.shape
-    _chk(1 <= n <= MAX_FUSED_BATCH, "batch size must be in 1..16")
+    _chk(1 <= n <= MAX_FUSED_BATCH, "batch size must be in 1..64")
     xh = _dev(x.to(torch.float16), "x")
     had, xpost, xsu = _rot_args(x_rot, xh, k)
     jobs = (nat.LutJob * len(layers))()
@@ -380,7 +380,7 @@ def _tcq_ok(S, KV):
     return S in _TCQ_KV and KV in _TCQ_KV[S]
 
 
-MAX_FUSED_BATCH = 16  # the reference's fused ops stop at 8; here 9..16 run as a second MFMA column group
+MAX_FUSED_BATCH = 64  # the reference's fused ops stop at 8; here a decoded step feeds up to 8 MFMA column groups of 8 rows
 
 
 def _shape_ok(m, n, k):

@@ -351,14 +351,21 @@ def test_llama70b_shapes(qp, oracle, qstr, k, m):
 
 @pytest.mark.parametrize("qstr,k,m", [("tcomb_6_7_0.5_none_0.9", 4096, 4096), ("tcq_8_none_0.9", 4096, 1024),
                                       ("ldlq_1_4_none_1.0", 4096, 2048), ("ldlq_2_12_none_1.0", 4096, 1024),
-                                      ("tcq_6_none_0.9", 14336, 4096)])
-def test_fused_skinny_gemm_batch_9_to_16(qp, oracle, qstr, k, m):
-    """Batches 9..16 run fused (second MFMA column group) instead of dequant + GEMM."""
+                                      ("tcq_6_none_0.9", 14336, 4096), ("tcq_6_none_0.9", 8192, 1024),
+                                      ("tcomb_6_7_0.5_none_0.9", 8192, 8192), ("ldlq_2_8_none_1.0", 4096, 1024)])
+def test_fused_skinny_gemm_batch_9_to_64(qp, oracle, qstr, k, m):
+    """Batches 9..64 run in the fused kernel too: one decoded step feeds 2 (16 waves per workgroup), 4 or 8 (8 waves) MFMA
+    column groups, x read from L2 — SURVEY N1 / north_star "batched dequant-then-GEMM tensor path", Llama-8B and 70B shapes.
+    Beyond the module's max_fused_batch (64; 32 where a 128 KiB codebook image leaves no room for 8 groups' reduction buffer)
+    the module decodes to fp16 and calls the fp16 GEMM, as the reference does for bs > 8 (lib/linear/tcq_linear.py:75-84)."""
     info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=5)
     layer = qp.make_linear_from_info(qstr, info).cuda()
+    assert layer.max_fused_batch == (32 if qstr.startswith("ldlq_2_12") else 64)
     W = _oracle_weight(oracle, qstr, info, m, k)
     gen = torch.Generator().manual_seed(9)
-    for n in (9, 13, 16):
+    for n in (9, 13, 16, 17, 31, 32, 33, 64):
+        if n > layer.max_fused_batch:
+            continue
         x = torch.randn(n, k, generator=gen).half()
         y = layer(x.cuda().float())
         assert y.dtype == torch.float32 and tuple(y.shape) == (n, m)
