@@ -52,6 +52,10 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="llama3.1-8b_tcomb_6_7", choices=sorted(WORKLOADS))
     ap.add_argument("--parallel", default="dp", choices=["dp", "tp"])
+    ap.add_argument("--gather", default="peer", choices=["peer", "rccl"],
+                    help="--parallel tp: how the row shards of o_proj / down_proj outputs are all-gathered. peer (default): one-shot "
+                         "direct peer writes over xGMI, one kernel inside the captured graph (csrc/peer_gather.hip); rccl: "
+                         "dist.all_gather_into_tensor, eager (the correctness baseline)")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--streams", type=int, default=1,
@@ -128,10 +132,11 @@ def build_model(qp, torch, model_key, qstr, nlayers, device, shard=None, distinc
             q0, simt0 = (q, simt) if q0 is None else (q0, simt0)
             assert (q, simt) == (q0, simt0), "fused layers must share the quantizer"
             k, m = li[key]["in_features"], li[key]["out_features"]
-            if shard is not None:
-                m = qp.shard.shard_rows(m, shard[1])[shard[0]]
-            infos.append(qp.mem_op.dummy_linear_info(k, m, q, seed=layer * 16 + LINEAR_ORDER.index(key), device=device,
-                                                     codebook_seed=cseed))
+            info = qp.mem_op.dummy_linear_info(k, m, q, seed=layer * 16 + LINEAR_ORDER.index(key), device=device,
+                                               codebook_seed=cseed)
+            if shard is not None:  # this rank's rows of the SAME full layer every rank generates (q|k|v by heads, ...)
+                info = qp.shard.shard_linear_info(info, shard[0], shard[1])
+            infos.append(info)
         cls = qp.linear.linear_class_for(q0, use_simt=False)
         info = infos[0]
         for other in infos[1:]:
@@ -204,11 +209,21 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
         if parts is not None:
             return token_chain()
         outs = []
+        if hasattr(gather, "new_token"):
+            gather.new_token()  # the same call sites take the same peer-gather slots in every (captured) token
         for groups in layers:
             pre = {}  # group index -> output buffer zeroed by an earlier launch of this block
             for gi, grp in enumerate(groups):
                 x = xs[grp[0][1]]
                 mods = [m for m, _, _ in grp]
+                if gather is not None and launch in ("multi", "chain") and n <= min(m.max_fused_batch for m in mods):
+                    # row-sharded model (--parallel tp): the same multi-job launches on every rank's shard; the outputs of
+                    # o_proj / down_proj feed full-width consumers (the next block's rotation): all-gather them.  q|k|v stay
+                    # head-sharded through attention, gate|up channel-sharded into down_proj's rotation input, which is
+                    # gathered as part of down's own input in a real model — here as its output slice.
+                    ys = qp.multi_gemv(mods, x)
+                    outs += [gather(y) for y in ys] if gi in (1, 3) else ys
+                    continue
                 if n > min(m.max_fused_batch for m in mods) and gather is None:
                     # beyond the fused batch: decode to fp16 W (staged 16-byte stores) + fp16 GEMM, as the reference does for
                     # bs > 8 (lib/linear/tcq_linear.py:75-84); the MFMA roofline of this path is reported by --batch
@@ -377,7 +392,13 @@ def main():
         for mod, k, _ in (u for grp in groups for u in grp):
             if k not in xs:
                 xs[k] = torch.randn(n, k, device=device).half()
-    gather = qp.shard.make_gatherer(world, device) if tp else None
+    gather = None
+    if tp:
+        if args.gather == "peer":
+            hidden = max(m.out_features for groups in layers for grp in (groups[1], groups[3]) for m, _, _ in grp)
+            gather = qp.shard.PeerGatherer(world, rank, device, max_bytes=n * hidden * 4, slots=2 * len(layers) + 2)
+        else:
+            gather = qp.shard.make_gatherer(world, device)
 
     main_stream = torch.cuda.Stream(device)
     side = [torch.cuda.Stream(device) for _ in range(2)] if args.streams >= 3 else []
@@ -455,7 +476,7 @@ def main():
     with torch.cuda.stream(main_stream):
         token()  # registers ops, sizes the allocator
         torch.cuda.synchronize()
-        if not args.no_graph and not tp:
+        if not args.no_graph and (not tp or isinstance(gather, qp.shard.PeerGatherer)):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=main_stream):
                 token()
@@ -571,7 +592,8 @@ def main():
                 args.distinct_codebooks else "one random codebook shared by all layers as in real checkpoints") + ")",
         "config": {"workload": f"{args.workload}: {nlayers} layers, {nlinear} quantized linears ({qstr}), batch {n}, "
                                f"{'HIP-graph replay' if graph is not None else 'eager'}, {args.streams} stream(s)",
-                   "parallelism": (f"tp{world} row-sharded + all-gather" if tp else f"dp{world} replicas"),
+                   "parallelism": (f"tp{world} row-sharded + " + ("one-shot peer-write gather (xGMI)" if isinstance(gather, qp.shard.PeerGatherer)
+                                                                   else "all-gather (torch.distributed)") if tp else f"dp{world} replicas"),
                    "linears_per_token": nlinear, "launches_per_token": nlaunch, "phases_per_token": nphase,
                    "launch_mode": args.launch,
                    "incoherent": bool(args.incoherent),

@@ -201,6 +201,18 @@ int qpal_pack_tcq_states(void *dst, const uint16_t *states, int m, int k, int KV
 int qpal_pack_lut_tc(void *dst, const int32_t *idx, int m, int k, int bits, int vec);
 int qpal_pack_lut_simt(void *dst, const int32_t *idx, int m, int k, int bits, int vec);
 
+/* One-shot all-gather of a small activation slice across the GPUs of a node by direct peer writes over xGMI (SURVEY.md §8e;
+ * no counterpart in the reference, which has no multi-GPU code): rank `rank` stores `bytes` bytes from src into
+ * peer_bufs[p] + rank * bytes for every p and raises a flag in peer_ws[p]; the call returns (in stream order) when all
+ * `world` slices have arrived in THIS rank's buffer peer_bufs[rank].  peer_bufs / peer_ws: HOST arrays of `world` device
+ * pointers — each rank's gather buffer of this call site (world * bytes bytes, 16-byte aligned) and flag block
+ * (QPAL_PEER_WS_BYTES_PER_SLOT * number of slots, zero-filled once), opened in every process through IPC handles.
+ * slot: index of the call site inside a token (buffers and flags are per call site).  world <= 16; bytes % 16 == 0.
+ * Graph-capturable (one kernel, epochs kept in the flag blocks).                                                         */
+#define QPAL_PEER_WS_BYTES_PER_SLOT 256
+int qpal_peer_gather(const void *src, long bytes, int slot, void *const *peer_bufs, void *const *peer_ws, int rank,
+                     int world, void *stream);
+
 /* 1 if the GEMV entry points can apply the rotation themselves (x_had): k in {2048, 4096} at batch 1 (the
  * decode case); 0 otherwise (then call qpal_hadamard first). */
 int qpal_can_fuse_rotation(int n, int k);

@@ -37,6 +37,7 @@ class ChainPhase(ctypes.Structure):
 
 
 CHAIN_WS_BYTES = 2048
+PEER_WS_BYTES_PER_SLOT = 256
 
 
 _SIGNATURES = {
@@ -58,6 +59,7 @@ _SIGNATURES = {
     "qpal_tcq_chain_build": [_P, ctypes.c_long, ctypes.POINTER(ChainPhase), _I, _I, _I, _I, _I, _I, _I],
     "qpal_lut_chain_build": [_P, ctypes.c_long, ctypes.POINTER(ChainPhase), _I, _I, _I, _I, _I],
     "qpal_chain_launch": [_P, _P, _P, _P, _P],
+    "qpal_peer_gather": [_P, ctypes.c_long, _I, ctypes.POINTER(_P), ctypes.POINTER(_P), _I, _I, _P],
 }
 
 

@@ -71,26 +71,26 @@ class CombLinearTCQ(_CombBase):
         if self.use_comb_kernel:
             return [f"decompress_gemm_tcq_comb_{self.out_features}_{bs}_{k}_{S}_{kv1}_{kv2}" for bs in B] + \
                    [f"decompress_tcq_comb_{S}_{kv1}_{kv2}"]
-        return [f"decompress_gemm_tcq_{self.out_part[i]}_{bs}_{k}_{S}_{kv}" for i, kv in enumerate((kv1, kv2)) for bs in B] + \
-               [f"decompress_tcq_{S}_{kv1}", f"decompress_tcq_{S}_{kv2}"]
+        return [f"decompress_gemm_tcq_{self.out_part[i]}_{bs}_{k}_{S}_{kv}" for i, kv in enumerate((kv1, kv2))
+                if self.out_part[i] > 0 for bs in B] + [f"decompress_tcq_{S}_{kv1}", f"decompress_tcq_{S}_{kv2}"]
 
     def _gemv(self, x, bs):
         k, S, (kv1, kv2) = self.in_features, self.tlut_bits, self.KV
         if self.use_comb_kernel:
             name = f"decompress_gemm_tcq_comb_{self.out_features}_{bs}_{k}_{S}_{kv1}_{kv2}"
             return op(name)(self.trellis1, self.trellis2, x, self.tlut)
-        y1 = op(f"decompress_gemm_tcq_{self.out_part[0]}_{bs}_{k}_{S}_{kv1}")(self.trellis1, x, self.tlut)
-        y2 = op(f"decompress_gemm_tcq_{self.out_part[1]}_{bs}_{k}_{S}_{kv2}")(self.trellis2, x, self.tlut)
-        return torch.cat([y1, y2], dim=1)
+        ys = [op(f"decompress_gemm_tcq_{mp}_{bs}_{k}_{S}_{kv}")(t, x, self.tlut)
+              for mp, kv, t in ((self.out_part[0], kv1, self.trellis1), (self.out_part[1], kv2, self.trellis2)) if mp > 0]
+        return ys[0] if len(ys) == 1 else torch.cat(ys, dim=1)  # a row shard may hold rows of one half only
 
     def get_weight(self):
         k, S, (kv1, kv2) = self.in_features, self.tlut_bits, self.KV
         if self.use_comb_kernel:
             return op(f"decompress_tcq_comb_{S}_{kv1}_{kv2}")(self.trellis1, self.trellis2, self.tlut,
                                                                self.out_features, k)
-        w1 = op(f"decompress_tcq_{S}_{kv1}")(self.trellis1, self.tlut, self.out_part[0], k)
-        w2 = op(f"decompress_tcq_{S}_{kv2}")(self.trellis2, self.tlut, self.out_part[1], k)
-        return torch.cat([w1, w2], dim=0)
+        ws = [op(f"decompress_tcq_{S}_{kv}")(t, self.tlut, mp, k)
+              for mp, kv, t in ((self.out_part[0], kv1, self.trellis1), (self.out_part[1], kv2, self.trellis2)) if mp > 0]
+        return ws[0] if len(ws) == 1 else torch.cat(ws, dim=0)
 
 
 class CombtLinearTCQ(_CombBase):

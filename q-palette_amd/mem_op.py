@@ -84,10 +84,12 @@ def _rand_i32(shape, gen, device):
     return torch.randint(-2 ** 31, 2 ** 31, shape, dtype=torch.int32, device=device, generator=gen)
 
 
-def dummy_linear_info(in_features, out_features, quantizer_str, seed=0, device="cpu", codebook_seed=None):
+def dummy_linear_info(in_features, out_features, quantizer_str, seed=0, device="cpu", codebook_seed=None, part=None):
     """Random packed weights with the reference's shapes/dtypes for one linear (``linear_info`` dict).
     codebook_seed: draw the codebook from its own generator (same seed -> same codebook in every layer, as in
-    real checkpoints where every layer carries a copy of one k-means codebook)."""
+    real checkpoints where every layer carries a copy of one k-means codebook).  part: (first, second) sizes of a comb /
+    tcomb layer's two halves when they are not equal (multiples of 32; the modules then run two single-stream ops,
+    lib/linear/comb_linear.py:91-102, 234-245)."""
     qi = get_quant_info(quantizer_str)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -114,14 +116,16 @@ def dummy_linear_info(in_features, out_features, quantizer_str, seed=0, device="
         return dict(common, KV=qi["KV"], trellis=trellis(out_features, in_features, qi["KV"]),
                     tlut=randn((2 ** qi["tlut_bits"], 2)))
     if quantizer_str.startswith("tcomb"):
-        assert qi["ratio"] == 0.5, "only support ratio = 0.5 for now"
-        part = (in_features // 2, in_features // 2)
+        assert qi["ratio"] == 0.5 or part is not None, "only support ratio = 0.5 for now"
+        part = tuple(part) if part is not None else (in_features // 2, in_features // 2)
+        assert sum(part) == in_features
         return dict(common, KV=qi["KV"], in_part=part,
                     trellis1=trellis(out_features, part[0], qi["KV"][0]),
                     trellis2=trellis(out_features, part[1], qi["KV"][1]), tlut=randn((2 ** qi["tlut_bits"], 2)))
     if quantizer_str.startswith("comb"):
-        assert qi["ratio"] == 0.5, "only support ratio = 0.5 for now"
-        part = (out_features // 2, out_features // 2)
+        assert qi["ratio"] == 0.5 or part is not None, "only support ratio = 0.5 for now"
+        part = tuple(part) if part is not None else (out_features // 2, out_features // 2)
+        assert sum(part) == out_features
         return dict(common, KV=qi["KV"], out_part=part,
                     trellis1=trellis(part[0], in_features, qi["KV"][0]),
                     trellis2=trellis(part[1], in_features, qi["KV"][1]), tlut=randn((2 ** qi["tlut_bits"], 2)))

@@ -43,7 +43,16 @@ def shard_linear_info(info, rank, world):
             per_row16 = kk // 16
             out[key] = info[key][r0 // 16 * per_row16: r1 // 16 * per_row16].contiguous()
     elif "out_part" in info:
-        raise NotImplementedError("row-split comb layers shard per half; shard the two halves separately")
+        # CombLinearTCQ: rows [0, out_part[0]) at KV[0] in trellis1, the rest at KV[1] in trellis2.  The shard [r0, r1) takes
+        # its rows from whichever halves it overlaps; the result is again a comb layer (possibly with an empty half, which
+        # the module handles as two single-stream ops — lib/linear/comb_linear.py:91-102)
+        per_row16 = k // 16
+        p0 = info["out_part"][0]
+        a0, a1 = min(r0, p0), min(r1, p0)            # rows of half 1
+        b0, b1 = max(r0, p0) - p0, max(r1, p0) - p0  # rows of half 2 (relative)
+        out["trellis1"] = info["trellis1"][a0 // 16 * per_row16: a1 // 16 * per_row16].contiguous()
+        out["trellis2"] = info["trellis2"][b0 // 16 * per_row16: b1 // 16 * per_row16].contiguous()
+        out["out_part"] = (a1 - a0, b1 - b0)
     elif "qweight" in info:  # [m, bits*k/32/vec]
         out["qweight"] = info["qweight"][r0:r1].contiguous()
     else:
@@ -52,17 +61,33 @@ def shard_linear_info(info, rank, world):
 
 
 def make_gatherer(world, device=None, group=None):
-    """-> f(y_local [n, m_local]) = y [n, m] (concatenation over ranks in rank order; equal shard sizes use
-    one all_gather_into_tensor, ragged sizes fall back to all_gather of padded slices)."""
+    """-> f(y_local [n, m_local]) = y [n, m] (concatenation over ranks in rank order) on torch.distributed collectives: equal
+    shard widths use one all_gather_into_tensor, ragged widths (out_features not a multiple of 32 * world) an all_gather of
+    padded slices.  The widths of a call site are exchanged once (first token) and cached; call f.new_token() at the start
+    of every token so that call sites keep their index."""
     if world == 1:
         return lambda y: y
+    sites, state = {}, {"i": 0}
 
     def gather(y):
+        i = state["i"]
+        state["i"] += 1
         n, ml = y.shape
-        buf = torch.empty((world * n, ml), dtype=y.dtype, device=y.device)  # rank-major concatenation
-        dist.all_gather_into_tensor(buf, y.contiguous(), group=group)
-        return buf.view(world, n, ml).permute(1, 0, 2).reshape(n, world * ml)
+        if i not in sites:
+            widths = [None] * world
+            dist.all_gather_object(widths, int(ml), group=group)
+            sites[i] = widths
+        widths = sites[i]
+        if len(set(widths)) == 1:
+            buf = torch.empty((world * n, ml), dtype=y.dtype, device=y.device)  # rank-major concatenation
+            dist.all_gather_into_tensor(buf, y.contiguous(), group=group)
+            return buf.view(world, n, ml).permute(1, 0, 2).reshape(n, world * ml)
+        return gather_ragged(y, widths, group=group)
 
+    def new_token():
+        state["i"] = 0
+
+    gather.new_token = new_token
     return gather
 
 
@@ -76,3 +101,85 @@ def gather_ragged(y, sizes, group=None):
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad, group=group)
     return torch.cat([b[:, :s] for b, s in zip(bufs, sizes)], dim=1)
+
+
+class PeerGatherer:
+    """All-gather by direct peer writes over xGMI (C-ABI qpal_peer_gather, csrc/peer_gather.hip): one kernel per call, inside
+    the captured graph, no library collective.  Every rank allocates `slots` gather buffers and one flag block and opens
+    every peer's through IPC handles exchanged with torch.distributed (any backend: the data path never touches it again).
+
+    Call sites: each call inside a token takes the next slot (buffers and flags are never shared between call sites, so a fast
+    rank cannot overwrite what a slow peer still reads); call `new_token()` before re-running or capturing a token so that
+    the same call sites map to the same slots.  RCCL's all_gather (`make_gatherer`) stays the correctness baseline."""
+
+    def __init__(self, world, rank, device, max_bytes, slots=64, group=None):
+        from . import _native as nat
+        self.nat = nat
+        self.world, self.rank, self.device = world, rank, torch.device(device)
+        self.max_bytes = (max_bytes + 15) // 16 * 16
+        self.slots = slots
+        self._next = 0
+        self._group = group
+        self._widths = {}  # call site -> per-rank slice widths (exchanged once, during the first, un-captured token)
+        self.bufs = torch.zeros(slots * world * self.max_bytes, dtype=torch.uint8, device=self.device)
+        self.ws = torch.zeros(slots * nat.PEER_WS_BYTES_PER_SLOT, dtype=torch.uint8, device=self.device)
+        torch.cuda.synchronize(self.device)
+        mine = (self.bufs.untyped_storage()._share_cuda_(), self.bufs.storage_offset(),
+                self.ws.untyped_storage()._share_cuda_(), self.ws.storage_offset())
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine, group=group)
+        self._peer_storages = []
+        self.peer_bufs, self.peer_ws = [], []
+        for r, (hb, ob, hw, ow) in enumerate(everyone):
+            if r == rank:
+                self.peer_bufs.append(self.bufs.data_ptr())
+                self.peer_ws.append(self.ws.data_ptr())
+                continue
+            sb = torch.UntypedStorage._new_shared_cuda(*hb)
+            sw = torch.UntypedStorage._new_shared_cuda(*hw)
+            self._peer_storages += [sb, sw]
+            self.peer_bufs.append(sb.data_ptr() + ob)
+            self.peer_ws.append(sw.data_ptr() + ow)
+        dist.barrier(group=group)
+
+    def new_token(self):
+        self._next = 0
+
+    def __call__(self, y):
+        import ctypes
+        n, ml = y.shape
+        y = y.contiguous()
+        nbytes = y.numel() * y.element_size()
+        assert nbytes % 16 == 0 and nbytes <= self.max_bytes and self._next < self.slots
+        slot = self._next
+        self._next += 1
+        if slot not in self._widths:
+            widths = [None] * self.world
+            dist.all_gather_object(widths, int(ml), group=self._group)
+            self._widths[slot] = widths
+        widths = self._widths[slot]
+        # every rank writes at rank * seg inside the slot's buffer; seg = the widest slice, so equal widths land contiguously
+        seg = max(widths) * n * y.element_size()
+        base = slot * self.world * self.max_bytes
+        arr_b = (ctypes.c_void_p * self.world)(*[b + base for b in self.peer_bufs])
+        arr_w = (ctypes.c_void_p * self.world)(*self.peer_ws)
+        with torch.cuda.device(self.device):
+            lib = self.nat.lib()
+            if len(set(widths)) == 1:
+                rc = lib.qpal_peer_gather(y.data_ptr(), nbytes, slot, arr_b, arr_w, self.rank, self.world,
+                                          torch.cuda.current_stream(self.device).cuda_stream)
+            else:  # ragged: pad the slice to the widest (the kernel's layout is rank * bytes)
+                pad = torch.zeros((n, max(widths)), dtype=y.dtype, device=y.device)
+                pad[:, :ml] = y
+                rc = lib.qpal_peer_gather(pad.data_ptr(), seg, slot, arr_b, arr_w, self.rank, self.world,
+                                          torch.cuda.current_stream(self.device).cuda_stream)
+        self.nat.check(rc, "qpal_peer_gather")
+        out = self.bufs[base: base + self.world * seg].view(y.dtype).view(self.world, n, max(widths))
+        if len(set(widths)) == 1:
+            return out.reshape(1, self.world * ml) if n == 1 else out.permute(1, 0, 2).reshape(n, self.world * ml)
+        return torch.cat([out[r, :, :w] for r, w in enumerate(widths)], dim=1)
+
+    def error(self):
+        """!= 0 after a synchronisation: a wait for a peer's flag gave up."""
+        return int(self.ws.view(torch.int32).view(self.slots, -1)[:, 32].abs().sum().item())
+

@@ -461,3 +461,48 @@ def test_reference_calling_pattern_under_torch_compile_and_graph_capture(qp, ora
     g.replay()
     torch.cuda.synchronize()
     _check_gemv(out.cpu().numpy(), W, xn.numpy(), oracle)
+
+
+@pytest.mark.parametrize("qstr,k,m,part", [("comb_6_7_0.5_none_0.9", 512, 256, (96, 160)), ("comb_7_8_0.5_none_0.9", 1024, 128, (32, 96)),
+                                            ("tcomb_6_7_0.5_none_0.9", 512, 256, (192, 320)), ("tcomb_3_4_0.5_none_0.9", 1024, 64, (768, 256))])
+def test_comb_layers_with_unequal_parts(qp, oracle, qstr, k, m, part):
+    """Comb / Combt with unequal halves cannot use the fused two-stream kernel (use_comb_kernel is False): the modules run two
+    single-stream ops and concatenate / add, like the reference (lib/linear/comb_linear.py:91-102, 234-245)."""
+    info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=3, part=part)
+    layer = qp.make_linear_from_info(qstr, info).cuda()
+    assert layer.use_comb_kernel is False
+    kv1, kv2 = info["KV"]
+    S = info["tlut_bits"]
+    tl = info["tlut"].numpy()
+    if "out_part" in info:
+        W = np.concatenate([oracle.tcq_dequant(info["trellis1"].numpy(), tl, part[0], k, S, kv1),
+                            oracle.tcq_dequant(info["trellis2"].numpy(), tl, part[1], k, S, kv2)], axis=0)
+    else:
+        W = np.concatenate([oracle.tcq_dequant(info["trellis1"].numpy(), tl, m, part[0], S, kv1),
+                            oracle.tcq_dequant(info["trellis2"].numpy(), tl, m, part[1], S, kv2)], axis=1)
+    assert np.array_equal(_bits(layer.get_weight()), W.view(np.uint16))
+    gen = torch.Generator().manual_seed(4)
+    for n in (1, 5, 16):
+        x = torch.randn(n, k, generator=gen).half()
+        y = layer(x.cuda().float())
+        # the column-split form adds two fp32 partial results: one more fp32 rounding than a single kernel
+        _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle)
+
+
+def test_comb_layer_row_shards(qp, oracle):
+    """shard_linear_info of a CombLinearTCQ: a row shard takes its rows from whichever halves it overlaps (possibly one);
+    the shards' outputs concatenate to the full layer's."""
+    qstr, k, m = "comb_6_7_0.5_none_0.9", 512, 256
+    info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=8)
+    full = qp.make_linear_from_info(qstr, info).cuda()
+    x = torch.randn(2, k, generator=torch.Generator().manual_seed(1)).cuda()
+    for world in (2, 4, 3):
+        parts = []
+        for r in range(world):
+            sh = qp.shard.shard_linear_info(info, r, world)
+            layer = qp.CombLinearTCQ.gen_layer_from_info(sh).cuda()
+            assert layer.out_features == qp.shard.shard_rows(m, world)[r]
+            parts.append(layer(x))
+        y = torch.cat(parts, dim=1)
+        ref = full(x)
+        assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max())), world
