@@ -36,9 +36,14 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
         for (int w = 0; w < grid * 16; w++) {
             if (h[w * 8] < t0) t0 = h[w * 8];
             if (h[w * 8 + 7] > t7) t7 = h[w * 8 + 7];
-            for (int i = 1; i < 8; i++) ph[i] += (double)(h[w * 8 + i] - h[w * 8 + i - 1]);
+            unsigned long long prev = h[w * 8];
+            for (int i = 1; i < 8; i++) {  // a stamp the path did not pass (early staging skips 2 and 3) reads 0: zero-length phase
+                const unsigned long long cur = h[w * 8 + i] ? h[w * 8 + i] : prev;
+                ph[i] += (double)(cur - prev);
+                prev = cur;
+            }
         }
-        printf("[stamps] grid %d m %d k %d wpr %d sk %d: span %.2f us (100MHz ticks); mean per-wave phase us:", grid, p.nrows * 32, p.k, 1 << p.log2_wpr, p.sk,
+        printf("[stamps] grid %d m %d k %d wpr %d sk %d: span %.2f (units of 100 shader cycles, s_memtime); mean per-wave phase:", grid, p.nrows * 32, p.k, 1 << p.log2_wpr, p.sk,
                (t7 - t0) / 100.0);
         const char *nm[8] = {"", "issue-w", "x+lut", "barrier", "steps", "xor-red", "barrier2", "final"};
         for (int i = 1; i < 8; i++) printf(" %s %.2f", nm[i], ph[i] / (grid * 16) / 100.0);
