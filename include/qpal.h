@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define QPAL_VERSION 200
+#define QPAL_VERSION 210
 
 #define QPAL_OK 0
 #define QPAL_E_SHAPE (-1)   /* m, k, n outside the supported set (m%32, k%32, 1<=n<=64 ...) */
@@ -73,12 +73,22 @@ typedef struct qpal_tcq_job {
     int kv;            /* 0: the call's KV1.  Otherwise this job's own KV (split NONE only): jobs of one S but different
                           bit widths — q, k, v of a mixed-scheme model — then share ONE launch and one codebook image
                           (KV 2..8 for S = 9, 8..10 for S = 10, 9..10 for S = 11; batch <= 8; no x_had) */
-    /* chain launches only (qpal_*_chain_build below; the per-launch entry points refuse x_f32 and ignore the flags): */
+    /* chain launches (qpal_*_chain_build below; the per-launch entry points take x_f32 only together with x_had, see the
+     * decoder-block fusion fields, and ignore the two flags): */
     const void *x_f32; /* fp32 [n][k] or NULL: the input is fp16(x_f32[i] * x_f32_scale), x_f32 being the fp32 output of an
                           EARLIER phase of the same chain (x may then be NULL) */
     float x_f32_scale; /* 0 is read as 1 */
     int x_fresh;       /* 1: x (fp16) is written by an earlier phase of the same chain */
     int publish;       /* 1: out is read (as x_f32) by a later phase of the same chain */
+    /* decoder-block fusion (per-launch entry points, x_had jobs): the rotation reads the fp32 residual stream and applies
+     * the RMSNorm in front of it (lib/linear/incoherent_linear.py:76-108 is called on `input_layernorm(h)` by the model,
+     * model/llama.py), and o_proj / down_proj add their result to it.  With x_had = 1: x_f32 (fp32 [k], 16-byte aligned) may
+     * replace x; x_rms_eps > 0 normalises x <- x * rsqrt(mean(x^2) + eps) * x_rms_w (fp16 [k] or NULL) in fp32 before the
+     * fp16 rounding and the sign flip.  accumulate = 1 (any job): out += result (out is the residual stream; with
+     * out_zeroed = 1 the launch may split K and add with atomics).                                                     */
+    float x_rms_eps;
+    const void *x_rms_w;
+    int accumulate;
 } qpal_tcq_job;
 /* prezero/prezero_bytes (may be NULL/0): a buffer this launch also fills with zeros, for a LATER launch on the
  * same stream that accumulates into it with atomics (split-K of a few-rows x long-K layer such as down_proj).
@@ -110,10 +120,13 @@ typedef struct qpal_lut_job {
     int x_had;            /* as in qpal_tcq_job */
     float x_post;
     const void *x_su;
-    const void *x_f32;    /* chain launches only, as in qpal_tcq_job */
+    const void *x_f32;    /* as in qpal_tcq_job */
     float x_f32_scale;
     int x_fresh;
     int publish;
+    float x_rms_eps;      /* as in qpal_tcq_job */
+    const void *x_rms_w;
+    int accumulate;
 } qpal_lut_job;
 int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits, int vec, void *prezero,
                            long prezero_bytes, void *stream);
@@ -212,6 +225,19 @@ int qpal_pack_lut_simt(void *dst, const int32_t *idx, int m, int k, int bits, in
 #define QPAL_PEER_WS_BYTES_PER_SLOT 256
 int qpal_peer_gather(const void *src, long bytes, int slot, void *const *peer_bufs, void *const *peer_ws, int rank,
                      int world, void *stream);
+
+/* Decoder-block glue of a batch-1 decode step, one launch: rotary embedding of the new token's q and k (HF rotate_half
+ * convention, cos / sin of pos * inv_freq rounded to fp16, fp16 arithmetic: model/llama.py apply_rotary_pos_emb), q as fp16,
+ * k and v written into a static KV cache fp16 [nkv][max_len][hd] at position *pos (device int64).  q / k / v: fp32 (the GEMV
+ * epilogue's output) [nq * hd] / [nkv * hd]; inv_freq: fp32 [hd / 2].                                                    */
+int qpal_rope_kv(const float *q, const float *k, const float *v, void *q_out_f16, void *kcache_f16, void *vcache_f16,
+                 const long *pos, const float *inv_freq, int nq, int nkv, int hd, long max_len, void *stream);
+
+/* Attention of ONE new token over a static KV cache (batch 1, grouped-query heads: nq % nkv == 0), one launch: softmax(q k^T *
+ * scale) v over positions 0 .. *pos, fp32 accumulation, fp16 out [nq][hd].  Caches fp16 [nkv][max_len][hd], 16-byte aligned.
+ * (torch SDPA runs this shape as ~10 launches.)  max_len up to ~40 k positions (scores live in LDS).                      */
+int qpal_attn_decode(const void *q_f16, const void *kcache_f16, const void *vcache_f16, void *out_f16, const long *pos,
+                     int nq, int nkv, int hd, long max_len, float scale, void *stream);
 
 /* 1 if the GEMV entry points can apply the rotation themselves (x_had): k in {2048, 4096} at batch 1 (the
  * decode case); 0 otherwise (then call qpal_hadamard first). */

@@ -95,7 +95,7 @@ class DecoderLayer(nn.Module):
         return h + self.mlp(self.post_attention_layernorm(h))
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="3_8b", choices=sorted(qp.mem_op.LAYER_INFO))
     ap.add_argument("--quantizer", default="tcomb_6_7_0.5_none_0.9")
@@ -104,7 +104,9 @@ def main():
     ap.add_argument("--context", type=int, default=1024, help="static KV-cache length attended over")
     ap.add_argument("--tokens", type=int, default=64)
     ap.add_argument("--vocab", type=int, default=128256)
-    args = ap.parse_args()
+    ap.add_argument("--no-fused", action="store_true", help="skip the fused-glue step (third figure)")
+    ap.add_argument("--no-modular", action="store_true", help="time the fused-glue step only (profiling)")
+    args = ap.parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("needs a GPU")
     dev = torch.device("cuda", 0)
@@ -176,8 +178,105 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / args.tokens
 
+    # ---- fused glue (MI355X decoder block): the residual stream stays fp32; RMSNorm + sign flip + Hadamard run inside the
+    # q|k|v and up|gate launches (x_rms / x_rot on the fp32 stream), o_proj and down_proj ADD into the stream (accumulate),
+    # rotary embedding + KV-cache write are one launch (qpal_rope_kv), attention over the cache one launch (qpal_attn_decode):
+    # 8 launches per layer instead of ~41.
+    nat = qp._native
+    h32 = torch.zeros(1, H, dtype=torch.float32, device=dev)
+    nq, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    q16 = torch.zeros(1, nq, 1, head_dim, dtype=torch.float16, device=dev)
+    a16 = torch.zeros(1, H, dtype=torch.float16, device=dev)
+    qkv32 = torch.zeros(1, H + 2 * kv_out, dtype=torch.float32, device=dev)
+    ug32 = torch.zeros(1, 2 * I, dtype=torch.float32, device=dev)
+    eps = layers[0].input_layernorm.eps
+
+    def fused_layer(idx, layer, mask):
+        att, mlp = layer.self_attn, layer.mlp
+        proj, wsc, blocks = att._qkv_layout()
+        widths = [l.out_features for l in proj]
+        qp.multi_gemv(proj, h32, outs=list(qkv32.split(widths, dim=1)), wscales=wsc, oscale=att.scale,
+                      x_rot=(att.SU_qkv, 1.0 / att.scale), x_rms=(eps, layer.input_layernorm.weight))
+        parts = dict(zip([b[0] for b in blocks], qkv32.split([b[1] for b in blocks], dim=1)))
+        with torch.cuda.device(dev):
+            rc = nat.lib().qpal_rope_kv(parts["q"].data_ptr(), parts["k"].data_ptr(), parts["v"].data_ptr(), q16.data_ptr(),
+                                        cache.k[idx].data_ptr(), cache.v[idx].data_ptr(), pos.data_ptr(), inv_freq.data_ptr(),
+                                        nq, nkv, head_dim, args.context, torch.cuda.current_stream(dev).cuda_stream)
+        nat.check(rc, "qpal_rope_kv")
+        with torch.cuda.device(dev):
+            rc = nat.lib().qpal_attn_decode(q16.data_ptr(), cache.k[idx].data_ptr(), cache.v[idx].data_ptr(), a16.data_ptr(),
+                                            pos.data_ptr(), nq, nkv, head_dim, args.context, 1.0 / math.sqrt(head_dim),
+                                            torch.cuda.current_stream(dev).cuda_stream)
+        nat.check(rc, "qpal_attn_decode")
+        qp.multi_gemv([att.o_proj], a16, outs=[h32], outs_zeroed=True, wscales=[att.Wscale_o], oscale=att.scale,
+                      x_rot=(att.SU_o, 1.0 / att.scale), accumulate=True)
+        inter = mlp.intermediate_size
+        if mlp.merge_ug:
+            ugl, ugw = [mlp.ug_proj], [mlp.Wscale_ug]
+        else:
+            ugl, ugw = [mlp.up_proj, mlp.gate_proj], [mlp.Wscale_ug[:inter], mlp.Wscale_ug[inter:]]
+        qp.multi_gemv(ugl, h32, outs=list(ug32.split([l.out_features for l in ugl], dim=1)), wscales=ugw, oscale=mlp.scale,
+                      x_rot=(mlp.SU_ug, 1.0 / mlp.scale), x_rms=(eps, layer.post_attention_layernorm.weight))
+        xr = qp.hadamard.rotate(ug32, hadK=mlp.had_left_dp_T, K=mlp.inter_K, su=mlp.SU_dp, post_scale=1.0 / mlp.scale,
+                                in_mode=qp.hadamard.IN_SWIGLU_F32)
+        qp.multi_gemv([mlp.down_proj], xr, outs=[h32], outs_zeroed=True, wscales=[mlp.Wscale_dp], oscale=mlp.scale,
+                      accumulate=True)
+
+    def fused_step():
+        h32.copy_(embed[tok].view(1, H))
+        mask = torch.where(ar <= pos, 0.0, float("-inf")).half().view(1, 1, 1, -1)
+        for idx, layer in enumerate(layers):
+            fused_layer(idx, layer, mask)
+        hn = norm(h32.half().view(1, 1, H))
+        logits = hn.view(1, H) @ lm_head.T
+        out_tok.copy_(logits.argmax(-1))
+        return hn
+
+    fusable = (not args.no_fused and H in (2048, 4096) and
+               all(qp.linear.rotation_fusable(l.self_attn._qkv_layout()[0], 1) and qp.linear.rotation_fusable([l.self_attn.o_proj], 1)
+                   and isinstance(l.mlp.down_proj, qp.linear._base.PackedLinearBase) and not isinstance(l.mlp.down_proj, qp.VQLinearPackSIMT)
+                   and qp.linear.rotation_fusable([l.mlp.ug_proj] if l.mlp.merge_ug else [l.mlp.up_proj, l.mlp.gate_proj], 1)
+                   for l in layers))
+
+    def timed_fused():
+        s = torch.cuda.Stream(dev)
+        with torch.cuda.stream(s):
+            fused_step()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                fused_step()
+            for i in range(4):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.tokens):
+                tok.copy_(out_tok)
+                pos.fill_(min(args.context - 1, 8 + i))
+                g.replay()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / args.tokens
+
+    # the fused step computes what the modular step computes (fp32 residual stream instead of fp16: small differences)
+    check = None
+    if fusable and not args.no_modular:
+        tok.zero_()
+        pos.fill_(3)
+        ref_h = norm(step(True).view(1, 1, H)).float()
+        tok.zero_()
+        pos.fill_(3)
+        got_h = fused_step().float()
+        check = {"max_abs_diff_final_norm": float((ref_h - got_h).abs().max()), "max_abs_ref": float(ref_h.abs().max())}
+    if args.no_modular:
+        if not fusable:
+            raise SystemExit("--no-modular: this configuration has no fused-glue step")
+        t_fused = timed_fused()
+        print(json.dumps({"model": args.model, "layers": nlayers, "quantizer": args.qdict or args.quantizer, "context": args.context,
+                          "tokens_per_s_fused_glue": 1.0 / t_fused, "ms_fused_glue": t_fused * 1e3}))
+        return {"ms_whole_step": None, "ms_fused_glue": t_fused * 1e3, "check": None}
     t_full = timed(True)
     t_proj = timed(False)
+    t_fused = timed_fused() if fusable else None
     finite = bool(torch.isfinite(step(True)).all())
     packed = sum(t.numel() * t.element_size() for m in layers.modules() for name in ("trellis", "trellis1", "trellis2", "qweight")
                  if (t := getattr(m, name, None)) is not None)
@@ -187,7 +286,9 @@ def main():
         "tokens_per_s_whole_step": 1.0 / t_full, "ms_whole_step": t_full * 1e3,
         "tokens_per_s_projections_only": 1.0 / t_proj, "ms_projections_only": t_proj * 1e3,
         "glue_ms": (t_full - t_proj) * 1e3, "packed_weight_GB": packed / 1e9, "lm_head_GB": lm_head.numel() * 2 / 1e9,
-        "finite": finite}))
+        "tokens_per_s_fused_glue": (1.0 / t_fused) if t_fused else None, "ms_fused_glue": t_fused * 1e3 if t_fused else None,
+        "fused_vs_modular": check, "finite": finite}))
+    return {"ms_whole_step": t_full * 1e3, "ms_fused_glue": t_fused * 1e3 if t_fused else None, "check": check}
 
 
 if __name__ == "__main__":

@@ -20,14 +20,16 @@ class TcqJob(ctypes.Structure):
     _fields_ = [("out", _P), ("c1", _P), ("c2", _P), ("x", _P), ("tlut", _P), ("m", _I), ("k", _I),
                 ("out_zeroed", _I), ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long),
                 ("x_had", _I), ("x_post", _F), ("x_su", _P), ("kv", _I),
-                ("x_f32", _P), ("x_f32_scale", _F), ("x_fresh", _I), ("publish", _I)]
+                ("x_f32", _P), ("x_f32_scale", _F), ("x_fresh", _I), ("publish", _I),
+                ("x_rms_eps", _F), ("x_rms_w", _P), ("accumulate", _I)]
 
 
 class LutJob(ctypes.Structure):
     """qpal_lut_job (include/qpal.h)"""
     _fields_ = [("out", _P), ("qweight", _P), ("x", _P), ("lut", _P), ("m", _I), ("k", _I), ("out_zeroed", _I),
                 ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long), ("x_had", _I), ("x_post", _F), ("x_su", _P),
-                ("x_f32", _P), ("x_f32_scale", _F), ("x_fresh", _I), ("publish", _I)]
+                ("x_f32", _P), ("x_f32_scale", _F), ("x_fresh", _I), ("publish", _I),
+                ("x_rms_eps", _F), ("x_rms_w", _P), ("accumulate", _I)]
 
 
 class ChainPhase(ctypes.Structure):
@@ -59,6 +61,8 @@ _SIGNATURES = {
     "qpal_tcq_chain_build": [_P, ctypes.c_long, ctypes.POINTER(ChainPhase), _I, _I, _I, _I, _I, _I, _I],
     "qpal_lut_chain_build": [_P, ctypes.c_long, ctypes.POINTER(ChainPhase), _I, _I, _I, _I, _I],
     "qpal_chain_launch": [_P, _P, _P, _P, _P],
+    "qpal_rope_kv": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_long, _P],
+    "qpal_attn_decode": [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_long, _F, _P],
     "qpal_peer_gather": [_P, ctypes.c_long, _I, ctypes.POINTER(_P), ctypes.POINTER(_P), _I, _I, _P],
 }
 

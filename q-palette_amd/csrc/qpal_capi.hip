@@ -53,10 +53,19 @@ int x_fits_lds(int n, int k) {
 bool rot_ok(int n, int k) { return n == 1 && (k == 2048 || k == 4096) && x_fits_lds(n, k); }
 
 // x_had of a job -> kernel parameters; QPAL_E_SHAPE where the fused rotation is not available
-int set_rotation(TcParams &p, int x_had, const void *x_su, float x_post, int n, int k) {
-    if (!x_had) return QPAL_OK;
+int set_rotation(TcParams &p, int x_had, const void *x_su, float x_post, int n, int k, const void *x_f32 = nullptr,
+                 float x_rms_eps = 0.f, const void *x_rms_w = nullptr) {
+    if (!x_had) return (x_f32 || x_rms_eps > 0.f) ? QPAL_E_PARAM : QPAL_OK;  // fp32 / normalised input: rotation staging only
     if (!rot_ok(n, k)) return QPAL_E_SHAPE;
     if (x_su && !aligned(x_su, 16)) return QPAL_E_ALIGN;
+    if (x_f32) {
+        p.x = static_cast<const uint16_t *>(x_f32);  // the staging reads it as fp32 (x_src_f32)
+        p.x_src_f32 = 1;
+    }
+    if (!p.x) return QPAL_E_NULL;
+    if (x_rms_w && !aligned(x_rms_w, 16)) return QPAL_E_ALIGN;
+    p.x_rms_eps = x_rms_eps > 0.f ? x_rms_eps : 0.f;
+    p.x_rms_w = static_cast<const uint16_t *>(x_rms_w);
     if (!aligned(p.x, 16)) return QPAL_E_ALIGN;
     p.x_rot = k / 1024;
     p.x_su = static_cast<const uint16_t *>(x_su);
@@ -310,9 +319,9 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         if (kv != KV1 && (split != QPAL_SPLIT_NONE || jb.x_had)) return QPAL_E_PARAM;
         int rc = tcq_check(jb.c1, jb.c2, jb.tlut, jb.m, jb.k, S, kv, KV2, split);
         if (rc) return rc;
-        if (!jb.out || !jb.x) return QPAL_E_NULL;
-        if (jb.x_f32) return QPAL_E_PARAM;  // chain launches only
-        if (!aligned(jb.x, 8) || !aligned(jb.out, 4) || (jb.k % 4)) return QPAL_E_ALIGN;
+        if (!jb.out || (!jb.x && !(jb.x_f32 && jb.x_had))) return QPAL_E_NULL;
+        if (jb.x_f32 && !jb.x_had) return QPAL_E_PARAM;  // fp32 input: rotation staging (or chain launches) only
+        if ((jb.x && !aligned(jb.x, 8)) || !aligned(jb.out, 4) || (jb.k % 4)) return QPAL_E_ALIGN;
         if (jb.wscale && !aligned(jb.wscale, 2)) return QPAL_E_ALIGN;
         if (jb.ldo != 0 && jb.ldo < jb.m) return QPAL_E_SHAPE;
         const long ldo = jb.ldo ? jb.ldo : jb.m;
@@ -322,15 +331,17 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
             tcq_fill(mp.job[j], jb.out, ldo, jb.c1, jb.c2, jb.x, jb.tlut, jb.m, n, jb.k, jb.k / 2, jb.k / 2, jb.wscale,
                      jb.oscale);
         mp.job[j].kv = kv;
-        rc = set_rotation(mp.job[j], jb.x_had, jb.x_su, jb.x_post, n, jb.k);
+        rc = set_rotation(mp.job[j], jb.x_had, jb.x_su, jb.x_post, n, jb.k, jb.x_f32, jb.x_rms_eps, jb.x_rms_w);
         if (rc) return rc;
+        mp.job[j].accumulate = jb.accumulate ? 1 : 0;
         zeroed[j] = jb.out_zeroed;
     }
     // the kernel stages (or rotates) x once per distinct x pointer: jobs that share x must agree on how
     for (int j = 1; j < njobs; j++)
         for (int i = 0; i < j; i++)
-            if (jobs[i].x == jobs[j].x && (jobs[i].x_had != jobs[j].x_had || jobs[i].x_su != jobs[j].x_su ||
-                                           jobs[i].x_post != jobs[j].x_post || jobs[i].k != jobs[j].k))
+            if (mp.job[i].x == mp.job[j].x &&
+                (jobs[i].x_had != jobs[j].x_had || jobs[i].x_su != jobs[j].x_su || jobs[i].x_post != jobs[j].x_post ||
+                 jobs[i].k != jobs[j].k || jobs[i].x_rms_eps != jobs[j].x_rms_eps || jobs[i].x_rms_w != jobs[j].x_rms_w))
                 return QPAL_E_PARAM;
     if (mixed) {
         if (n > 8) return QPAL_E_SHAPE;
@@ -418,7 +429,7 @@ static int lut_args_ok(const void *out, const void *qweight, const void *x, cons
 
 int qpal_lut_tc_gemv(float *out, const void *qweight, const void *x, const void *lut, int m, int n, int k, int bits,
                      int vec, void *stream) {
-    qpal_lut_job job{out, qweight, x, lut, m, k, 0, nullptr, 1.0f, 0, 0, 1.0f, nullptr, nullptr, 1.0f, 0, 0};
+    qpal_lut_job job{out, qweight, x, lut, m, k, 0, nullptr, 1.0f, 0, 0, 1.0f, nullptr, nullptr, 1.0f, 0, 0, 0.0f, nullptr, 0};
     return qpal_lut_tc_gemv_multi(&job, 1, n, bits, vec, nullptr, 0, stream);
 }
 
@@ -433,20 +444,22 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
     int zeroed[kMaxJobs] = {0};
     for (int j = 0; j < njobs; j++) {
         const qpal_lut_job &jb = jobs[j];
-        int rc = lut_args_ok(jb.out, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k, bits, vec);
+        int rc = lut_args_ok(jb.out, jb.qweight, jb.x ? jb.x : (jb.x_had ? jb.x_f32 : nullptr), jb.lut, jb.m, n, jb.k, bits, vec);
         if (rc) return rc;
-        if (jb.x_f32) return QPAL_E_PARAM;  // chain launches only
+        if (jb.x_f32 && !jb.x_had) return QPAL_E_PARAM;  // fp32 input: rotation staging (or chain launches) only
         if (jb.wscale && !aligned(jb.wscale, 2)) return QPAL_E_ALIGN;
         if (jb.ldo != 0 && jb.ldo < jb.m) return QPAL_E_SHAPE;
         lut_fill(mp.job[j], jb.out, jb.ldo ? jb.ldo : jb.m, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k, jb.wscale, jb.oscale);
-        rc = set_rotation(mp.job[j], jb.x_had, jb.x_su, jb.x_post, n, jb.k);
+        rc = set_rotation(mp.job[j], jb.x_had, jb.x_su, jb.x_post, n, jb.k, jb.x_f32, jb.x_rms_eps, jb.x_rms_w);
         if (rc) return rc;
+        mp.job[j].accumulate = jb.accumulate ? 1 : 0;
         zeroed[j] = jb.out_zeroed;
     }
     for (int j = 1; j < njobs; j++)
         for (int i = 0; i < j; i++)
-            if (jobs[i].x == jobs[j].x && (jobs[i].x_had != jobs[j].x_had || jobs[i].x_su != jobs[j].x_su ||
-                                           jobs[i].x_post != jobs[j].x_post || jobs[i].k != jobs[j].k))
+            if (mp.job[i].x == mp.job[j].x &&
+                (jobs[i].x_had != jobs[j].x_had || jobs[i].x_su != jobs[j].x_su || jobs[i].x_post != jobs[j].x_post ||
+                 jobs[i].k != jobs[j].k || jobs[i].x_rms_eps != jobs[j].x_rms_eps || jobs[i].x_rms_w != jobs[j].x_rms_w))
                 return QPAL_E_PARAM;
     mp.zero = static_cast<u32x4 *>(prezero);
     mp.zero_chunks = (int)(prezero_bytes / 16);

@@ -65,6 +65,12 @@ struct TcParams {
     float x_f32_scale;
     int x_fresh;             // x (fp16) was written by an earlier phase of this launch: agent-scope loads
     int publish;             // out is read by a later phase of this launch: agent-scope (write-through) stores
+    // decoder-block fusion (x_rot jobs of the per-launch kernels): the rotation's input may be the fp32 residual stream
+    // with RMSNorm applied on the way in, and the projection may accumulate into its output (the residual add)
+    int x_src_f32;           // x points at fp32 [k] (not fp16)
+    float x_rms_eps;         // > 0: x <- x * rsqrt(mean(x^2) + eps) (* x_rms_w) before the sign flip (fp32, then ONE fp16 rounding)
+    const uint16_t *x_rms_w; // fp16 [k] RMSNorm weight or null
+    int accumulate;          // out += result instead of out = result
 };
 
 constexpr int kMaxJobs = 8;
@@ -587,10 +593,57 @@ __global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const u
                             dst[i] = __builtin_bit_cast(uint16_t, (_Float16)((float)(_Float16)v * p.x_post));
                         };
                     };
+                    wht_float4 *d1buf = reinterpret_cast<wht_float4 *>(xs + ((total + 32 + 7) & ~7));  // <= 16 KiB
+                    // RMSNorm fused into the rotation's input (decoder-block fusion): the sum of squares first (x is 8-16 KiB,
+                    // L2-resident: a second read beats a launch of its own), then every loaded element is scaled in fp32
+                    float inv_rms = 1.0f;
+                    if (p.x_rms_eps > 0.f) {
+                        float ss = 0.f;
+                        for (int i = tid * 4; i < total; i += NT * 4) {
+                            float f[4];
+                            if (p.x_src_f32) {
+                                const float4_t v = *reinterpret_cast<const float4_t *>(reinterpret_cast<const float *>(p.x) + i);
+                                f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+                            } else {
+                                const u32x2 v = *reinterpret_cast<const u32x2 *>(p.x + i);
+                                const h2_t a = __builtin_bit_cast(h2_t, v.x), b = __builtin_bit_cast(h2_t, v.y);
+                                f[0] = (float)a[0]; f[1] = (float)a[1]; f[2] = (float)b[0]; f[3] = (float)b[1];
+                            }
+                            ss += f[0] * f[0] + f[1] * f[1] + f[2] * f[2] + f[3] * f[3];
+                        }
+#pragma unroll
+                        for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+                        float *part = reinterpret_cast<float *>(d1buf + 4 * 4 * 64);
+                        if (lane == 0) part[wave] = ss;
+                        __syncthreads();
+                        float tot = 0.f;
+#pragma unroll
+                        for (int wv = 0; wv < W; wv++) tot += part[wv];
+                        inv_rms = __builtin_amdgcn_rsqf(tot / (float)total + p.x_rms_eps);
+                    }
                     auto load_row = [&](const uint16_t *xrow) {
                         return [=](int t, int kc) {
                             const int off = (16 * t + (lane & 15)) * 64 + 32 * kc + 8 * (lane >> 4);
-                            wht_half8 h = *reinterpret_cast<const wht_half8 *>(xrow + off);
+                            wht_half8 h;
+                            if (p.x_src_f32 || p.x_rms_eps > 0.f) {
+                                float f[8];
+                                if (p.x_src_f32) {
+                                    const float *xf = reinterpret_cast<const float *>(xrow) + off;
+                                    const float4_t v0 = *reinterpret_cast<const float4_t *>(xf), v1 = *reinterpret_cast<const float4_t *>(xf + 4);
+#pragma unroll
+                                    for (int e = 0; e < 4; e++) { f[e] = v0[e]; f[4 + e] = v1[e]; }
+                                } else {
+                                    const wht_half8 hx = *reinterpret_cast<const wht_half8 *>(xrow + off);
+#pragma unroll
+                                    for (int e = 0; e < 8; e++) f[e] = (float)hx[e];
+                                }
+                                wht_half8 wgt;
+                                if (p.x_rms_w) wgt = *reinterpret_cast<const wht_half8 *>(p.x_rms_w + off);
+#pragma unroll
+                                for (int e = 0; e < 8; e++) h[e] = (_Float16)(f[e] * inv_rms * (p.x_rms_w ? (float)wgt[e] : 1.0f));
+                            } else {
+                                h = *reinterpret_cast<const wht_half8 *>(xrow + off);
+                            }
                             if (p.x_su) h = h * *reinterpret_cast<const wht_half8 *>(p.x_su + off);
                             return h;
                         };
@@ -600,7 +653,6 @@ __global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const u
                     // instructions; the codebook image is built by the waves that have no stage-1 tile.
                     // (Alternatives measured slower: one wave quad rotating straight from global memory, +2.0 us per
                     // launch; x * su staged in LDS first, two more barriers.)
-                    wht_float4 *d1buf = reinterpret_cast<wht_float4 *>(xs + ((total + 32 + 7) & ~7));  // <= 16 KiB
                     if (p.x_rot == 4) wht64_wg_stage1<4>(wave, lane, d1buf, load_row(p.x));
                     else wht64_wg_stage1<2>(wave, lane, d1buf, load_row(p.x));
                     if (p.tab != cur_tab) {
@@ -688,8 +740,9 @@ __global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const u
                     for (int qq = 0; qq < wpr; qq++) v += red[(((rl << p.log2_wpr) + qq) * p.n + b) * 32 + r];
                     float *dst = p.out + (long)b * p.ldo + (long)srow * 32 + r;
                     v *= osc;
-                    if (p.sk == 1) *dst = v;
-                    else atomicAdd(dst, v);
+                    if (p.sk > 1) atomicAdd(dst, v);
+                    else if (p.accumulate) *dst += v;  // the residual add of a decoder block: out is the fp32 residual stream
+                    else *dst = v;
                 }
             }
         }

@@ -92,7 +92,8 @@ def rotation_fusable(layers, n):
             and ops.can_fuse_rotation(n, layers[0].in_features))
 
 
-def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=None, oscale=1.0, x_rot=None):
+def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=None, oscale=1.0, x_rot=None, x_rms=None,
+               accumulate=False):
     """y_i = layers[i](x) for several quantized linears that share the input, batch <= 8.  Layers of one
     kind and codec (e.g. q|k|v or gate|up of one block) go out as ONE kernel launch per codec
     (C-ABI qpal_*_gemv_multi); anything else is one launch per layer.  Returns fp32/fp16 [n, m_i] tensors in
@@ -104,13 +105,15 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
     wscales (fp16 [m_i] vectors) / oscale: y_i = layers[i](x) * wscales[i] * oscale, fused into the GEMV epilogue for
     the tensor-core-order families (the `* Wscale * scale` of the incoherent wrappers).
     x_rot = (su, post_scale): x is the UN-rotated input and every launch stages fp16(fp16(H (x*su)/sqrt(k)) * post)
-    itself (only where rotation_fusable(layers, n))."""
+    itself (only where rotation_fusable(layers, n)); x may then be the fp32 residual stream, and x_rms = (eps, weight or
+    None) applies the RMSNorm in front of the rotation (decoder-block fusion).  accumulate: outs[i] += y_i (the residual add:
+    outs[i] holds the residual stream; with outs_zeroed=True the launch may split K and add with atomics)."""
     from .. import ops
 
     x2 = x.reshape(-1, layers[0].in_features)
     n = x2.shape[0]
     if n > min(l.max_fused_batch for l in layers):  # decode-to-fp16 + GEMM path of the modules: the fused-launch extras have no meaning there
-        if outs is not None or prezero is not None or wscales is not None or oscale != 1.0 or x_rot is not None:
+        if outs is not None or prezero is not None or wscales is not None or oscale != 1.0 or x_rot is not None or accumulate:
             raise RuntimeError("multi_gemv: outs / prezero / wscales / oscale / x_rot need a fused batch (n <= 64)")
         return [l(x2) for l in layers]
     results = [None] * len(layers)
@@ -121,7 +124,8 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
         grp = [layers[i] for i in idxs]
         o = [outs[i] for i in idxs] if outs is not None else None
         ws = [wscales[i] for i in idxs] if wscales is not None else None
-        extra = dict(outs=o, outs_zeroed=outs_zeroed, prezero=prezero, wscales=ws, oscale=oscale, x_rot=x_rot)
+        extra = dict(outs=o, outs_zeroed=outs_zeroed, prezero=prezero, wscales=ws, oscale=oscale, x_rot=x_rot, x_rms=x_rms,
+                     accumulate=accumulate)
         if kind == "tcq":
             ys = ops.tcq_gemv_multi([(l.trellis, None, l.tlut, l.out_features, l.KV) for l in grp], x2, first.tlut_bits,
                                     first.KV, **extra)
@@ -135,8 +139,8 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
                                        first.vec_sz, **extra)
             prezero = None
         else:
-            if x_rot is not None:
-                raise RuntimeError("x_rot needs tensor-core-order packed layers (see rotation_fusable)")
+            if x_rot is not None or accumulate:
+                raise RuntimeError("x_rot / accumulate need tensor-core-order packed layers (see rotation_fusable)")
             ys = [first._gemv(x2, n) if n <= first.max_fused_batch else first(x2)]
             if ws is not None and ws[0] is not None:
                 ys = [ys[0].float() * ws[0].float() * oscale]

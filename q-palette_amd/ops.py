@@ -275,8 +275,26 @@ def can_fuse_rotation(n, k):
     return bool(nat.lib().qpal_can_fuse_rotation(int(n), int(k)))
 
 
+def _x_arg(x, x_rot):
+    """-> (fp16 x or None, fp32 x or None): with x_rot the rotation staging also takes the fp32 residual stream as it is."""
+    if x_rot is not None and x.dtype == torch.float32:
+        return None, _dev(x, "x")
+    return _dev(x.to(torch.float16), "x"), None
+
+
+def _rms_args(x_rms, k):
+    """x_rms = (eps, weight fp16 [k] or None): RMSNorm applied in front of the fused rotation."""
+    if x_rms is None:
+        return 0.0, None
+    eps, w = x_rms
+    if w is not None:
+        _chk(w.is_cuda and w.is_contiguous() and w.dtype == torch.float16 and w.numel() == k,
+             f"x_rms weight must be a contiguous fp16 CUDA vector of {k} elements")
+    return float(eps), (w.data_ptr() if w is not None else None)
+
+
 def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=False, prezero=None, wscales=None,
-                   oscale=1.0, x_rot=None):
+                   oscale=1.0, x_rot=None, x_rms=None, accumulate=False):
     """Several TCQ GEMVs of one codec and one input in ONE launch (C-ABI qpal_tcq_gemv_multi).
     streams: list of (c1, c2_or_None, tlut, m) or (c1, None, tlut, m, KV): with per-stream KV, single-stream layers of one
     codebook size but different bit widths share the launch.  x: [n, k].  Returns the list of fp32 [n, m] outputs.
@@ -286,10 +304,12 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
     x_rot = (su, post): x is the un-rotated input; the kernel stages fp16(fp16(H (x * su) / sqrt(k)) * post) itself."""
     n, k = x.shape
     _chk(1 <= n <= MAX_FUSED_BATCH, "batch size must be in 1..64")
-    xh = _dev(x.to(torch.float16), "x")
-    had, xpost, xsu = _rot_args(x_rot, xh, k)
+    xh, x32 = _x_arg(x, x_rot)
+    had, xpost, xsu = _rot_args(x_rot, x, k)
+    rms_eps, rms_w = _rms_args(x_rms, k)
+    _chk(x_rms is None or x_rot is not None, "x_rms needs x_rot (the RMSNorm is fused into the rotation's input)")
     jobs = (nat.TcqJob * len(streams))()
-    results, keep = [], [xh]
+    results, keep = [], [xh, x32]
     for j, stream in enumerate(streams):
         c1, c2, tlut, m = stream[:4]
         kv = stream[4] if len(stream) > 4 else 0
@@ -304,8 +324,10 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
             _tcq_stream_ok(c2, m, k // 2, KV2, "compressed2")
         out = _out_arg(outs, j, n, m, x.device)
         jobs[j] = nat.TcqJob(out.data_ptr(), c1.data_ptr(), c2.data_ptr() if c2 is not None else None,
-                             xh.data_ptr(), tl.data_ptr(), m, k, 1 if (outs is not None and outs_zeroed) else 0,
-                             _wscale_arg(wscales, j, m), float(oscale), _ldo(out, n, m), had, xpost, xsu, kv)
+                             xh.data_ptr() if xh is not None else None, tl.data_ptr(), m, k,
+                             1 if (outs is not None and outs_zeroed) else 0,
+                             _wscale_arg(wscales, j, m), float(oscale), _ldo(out, n, m), had, xpost, xsu, kv,
+                             x32.data_ptr() if x32 is not None else None, 1.0, 0, 0, rms_eps, rms_w, 1 if accumulate else 0)
         results.append(out)
         keep += [c1, c2, tl]
     zp, zb = _prezero_args(prezero)
@@ -316,21 +338,24 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
 
 
 def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezero=None, wscales=None, oscale=1.0,
-                      x_rot=None):
+                      x_rot=None, x_rms=None, accumulate=False):
     """Several VQ/SQ (tensor-core packing) GEMVs of one codec and one input in ONE launch.
     layers: list of (qweight, lut, m); x: [n, k].  outs / outs_zeroed / prezero as in tcq_gemv_multi."""
     n, k = x.shape
     _chk(1 <= n <= MAX_FUSED_BATCH, "batch size must be in 1..64")
-    xh = _dev(x.to(torch.float16), "x")
-    had, xpost, xsu = _rot_args(x_rot, xh, k)
+    xh, x32 = _x_arg(x, x_rot)
+    had, xpost, xsu = _rot_args(x_rot, x, k)
+    rms_eps, rms_w = _rms_args(x_rms, k)
+    _chk(x_rms is None or x_rot is not None, "x_rms needs x_rot (the RMSNorm is fused into the rotation's input)")
     jobs = (nat.LutJob * len(layers))()
-    results, keep = [], [xh]
+    results, keep = [], [xh, x32]
     for j, (q, lut, m) in enumerate(layers):
         q, cb = _lut_args(q, lut, m, k, bits, vec)
         out = _out_arg(outs, j, n, m, x.device)
-        jobs[j] = nat.LutJob(out.data_ptr(), q.data_ptr(), xh.data_ptr(), cb.data_ptr(), m, k,
+        jobs[j] = nat.LutJob(out.data_ptr(), q.data_ptr(), xh.data_ptr() if xh is not None else None, cb.data_ptr(), m, k,
                              1 if (outs is not None and outs_zeroed) else 0, _wscale_arg(wscales, j, m), float(oscale),
-                             _ldo(out, n, m), had, xpost, xsu)
+                             _ldo(out, n, m), had, xpost, xsu, x32.data_ptr() if x32 is not None else None, 1.0, 0, 0,
+                             rms_eps, rms_w, 1 if accumulate else 0)
         results.append(out)
         keep += [q, cb]
     zp, zb = _prezero_args(prezero)

@@ -1,0 +1,105 @@
+"""GPU tests of the decoder-block glue (csrc/decoder_glue.hip) and of the fused decode step of perf/decode_llama.py:
+rotary embedding + KV-cache write and single-token attention against plain torch, RMSNorm / fp32-residual fusion of the GEMV
+launches against the modular Incoherent* path.  Reference counterparts: model/llama.py apply_rotary_pos_emb + StaticCache
+update + SDPA, lib/linear/incoherent_linear.py:76-108, 317-338."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def qp():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import qpalette_amd
+    qpalette_amd._native.lib()
+    return qpalette_amd
+
+
+def _rotate_half(x):
+    x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+@pytest.mark.parametrize("nq,nkv,hd,ctx,pos", [(32, 8, 128, 256, 17), (8, 8, 64, 64, 0), (64, 8, 128, 2048, 2047)])
+def test_rope_kv_and_attn_decode_match_torch(qp, nq, nkv, hd, ctx, pos):
+    dev = torch.device("cuda", 0)
+    nat = qp._native
+    gen = torch.Generator(device=dev).manual_seed(nq + pos)
+    q32 = torch.randn(nq * hd, device=dev, generator=gen)
+    k32 = torch.randn(nkv * hd, device=dev, generator=gen)
+    v32 = torch.randn(nkv * hd, device=dev, generator=gen)
+    kc = (torch.randn(nkv, ctx, hd, device=dev, generator=gen) * 0.5).half()
+    vc = (torch.randn(nkv, ctx, hd, device=dev, generator=gen) * 0.5).half()
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    inv_freq = 1.0 / (500000.0 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
+    pos_t = torch.tensor([pos], dtype=torch.long, device=dev)
+    q16 = torch.empty(nq * hd, dtype=torch.float16, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    nat.check(nat.lib().qpal_rope_kv(q32.data_ptr(), k32.data_ptr(), v32.data_ptr(), q16.data_ptr(), kc.data_ptr(), vc.data_ptr(),
+                                     pos_t.data_ptr(), inv_freq.data_ptr(), nq, nkv, hd, ctx, stream), "qpal_rope_kv")
+    # torch reference: the reference's fp16 pipeline (model/llama.py apply_rotary_pos_emb on .half() inputs)
+    ang = pos_t.float()[:, None] * inv_freq[None, :]
+    emb = torch.cat((ang, ang), dim=-1)
+    cos, sin = emb.cos().half(), emb.sin().half()
+    qh, kh = q32.half().view(nq, hd), k32.half().view(nkv, hd)
+    q_ref = qh * cos + _rotate_half(qh) * sin
+    k_ref = kh * cos + _rotate_half(kh) * sin
+    kc_ref[:, pos] = k_ref
+    vc_ref[:, pos] = v32.half().view(nkv, hd)
+    torch.cuda.synchronize()
+    assert torch.allclose(q16.view(nq, hd).float(), q_ref.float(), atol=4e-3, rtol=2e-3)  # sincos in fp32 vs torch's: <= 1 fp16 ulp
+    assert torch.allclose(kc.float(), kc_ref.float(), atol=4e-3, rtol=2e-3) and torch.equal(vc, vc_ref)
+    out = torch.empty(nq * hd, dtype=torch.float16, device=dev)
+    nat.check(nat.lib().qpal_attn_decode(q16.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(), pos_t.data_ptr(), nq, nkv, hd,
+                                         ctx, 1.0 / math.sqrt(hd), stream), "qpal_attn_decode")
+    qf = q16.view(1, nq, 1, hd).float()
+    kf = kc[:, : pos + 1].float().repeat_interleave(nq // nkv, dim=0)[None]
+    vf = vc[:, : pos + 1].float().repeat_interleave(nq // nkv, dim=0)[None]
+    ref = torch.softmax(qf @ kf.transpose(-1, -2) / math.sqrt(hd), dim=-1) @ vf
+    torch.cuda.synchronize()
+    assert torch.allclose(out.view(nq, hd).float(), ref.view(nq, hd), atol=2e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("qstr", ["tcomb_6_7_0.5_none_0.9", "ldlq_2_8_none_1.0"])
+def test_rmsnorm_fp32_stream_and_accumulate_in_the_gemv_launch(qp, qstr):
+    """multi_gemv(..., x = fp32 residual stream, x_rot, x_rms) == rotate(rmsnorm(x).half()) then GEMV; accumulate adds into out."""
+    dev = torch.device("cuda", 0)
+    k, m = 4096, 1024
+    layer = qp.make_linear_from_info(qstr, qp.mem_op.dummy_linear_info(k, m, qstr, seed=2)).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    h32 = torch.randn(1, k, device=dev, generator=gen) * 3.0
+    w_ln = (1.0 + 0.1 * torch.randn(k, device=dev, generator=gen)).half()
+    su = (torch.randint(0, 2, (k,), device=dev, generator=gen) * 2 - 1).half()
+    wsc = (0.01 + 0.01 * torch.rand(m, device=dev, generator=gen)).half()
+    eps, scale = 1e-5, 64.0
+    x_norm = torch.nn.functional.rms_norm(h32, (k,), w_ln.float(), eps).half()   # fp32 norm, one fp16 rounding (the reference)
+    xr = qp.hadamard.rotate(x_norm, su=su, post_scale=1.0 / scale)
+    (ref,) = qp.multi_gemv([layer], xr, wscales=[wsc], oscale=scale)
+    (got,) = qp.multi_gemv([layer], h32, wscales=[wsc], oscale=scale, x_rot=(su, 1.0 / scale), x_rms=(eps, w_ln))
+    torch.cuda.synchronize()
+    tol = 2.0 ** -9 * float(ref.abs().max())  # rsqrt / summation-order differences move a few inputs by one fp16 ulp
+    assert torch.allclose(got, ref, atol=tol, rtol=2e-3), float((got - ref).abs().max())
+    acc = torch.full((1, m), 0.5, device=dev)
+    qp.multi_gemv([layer], h32, outs=[acc], outs_zeroed=True, wscales=[wsc], oscale=scale, x_rot=(su, 1.0 / scale),
+                  x_rms=(eps, w_ln), accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.allclose(acc, got + 0.5, atol=tol, rtol=2e-3)
+
+
+def test_fused_decode_step_matches_modular_step(qp):
+    """perf/decode_llama.py: the fused-glue step (8 launches per layer) and the modular Incoherent* step (torch glue) produce the
+    same normalised hidden state for the same random 2-layer Llama-3.1-8B-shaped model."""
+    sys.path.insert(0, os.path.join(ROOT, "perf"))
+    import decode_llama
+    res = decode_llama.main(["--layers", "2", "--tokens", "4", "--context", "128", "--vocab", "4096"])
+    chk = res["check"]
+    assert chk is not None and res["ms_fused_glue"] is not None
+    assert chk["max_abs_diff_final_norm"] <= 2.0 ** -7 * max(1.0, chk["max_abs_ref"]), chk
