@@ -30,12 +30,16 @@ def main():
     ap.add_argument("--part", type=int, default=0)
     ap.add_argument("--parts", type=int, default=1)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--only", default=None, help="regular expression on the key (re-measure a few entries)")
     args = ap.parse_args()
     import torch
     import qpalette_amd as qp
 
     dev = torch.device("cuda", 0)
     keys = [(lk, q, simt) for q in QUANTIZERS for lk in SHAPES for simt in ((False, True) if q.startswith("ldlq") else (False,))]
+    if args.only:
+        import re
+        keys = [k for k in keys if re.search(args.only, f"{k[0]}_{k[1]}_{k[2]}")]
     keys = keys[args.part::args.parts]
     done = set()
     if os.path.exists(args.out):

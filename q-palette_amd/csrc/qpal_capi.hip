@@ -505,10 +505,7 @@ int qpal_lut_simt_gemv(void *out_f16, const void *qweight, const void *x, const 
         return QPAL_E_ALIGN;
     SimtParams p{static_cast<uint16_t *>(out_f16), static_cast<const uint32_t *>(qweight),
                  static_cast<const uint16_t *>(x), lut, n, m, k};
-    const int pairs = (m + 1) / 2;
-    int grid = (pairs + 15) / 16;
-    if (grid > kNumCU) grid = kNumCU;
-    return launch_simt_gemv(p, bits, vec, nb_of(n), grid, static_cast<hipStream_t>(stream));
+    return launch_simt_gemv(p, bits, vec, nb_of(n), simt_gemv_geometry(m, n, k, bits, vec, kNumCU), static_cast<hipStream_t>(stream));
 }
 
 int qpal_lut_simt_dequant(void *out_f16, const void *qweight, const void *lut, int m, int k, int bits, int vec,

@@ -3,17 +3,17 @@
 
 namespace qpal {
 
-int launch_simt_gemv_nb1(const SimtParams &p, int bits, int vec, int grid, hipStream_t stream);
-int launch_simt_gemv_nb2(const SimtParams &p, int bits, int vec, int grid, hipStream_t stream);
-int launch_simt_gemv_nb4(const SimtParams &p, int bits, int vec, int grid, hipStream_t stream);
-int launch_simt_gemv_nb8(const SimtParams &p, int bits, int vec, int grid, hipStream_t stream);
+int launch_simt_gemv_nb1(const SimtParams &p, int bits, int vec, const SimtGeometry &g, hipStream_t stream);
+int launch_simt_gemv_nb2(const SimtParams &p, int bits, int vec, const SimtGeometry &g, hipStream_t stream);
+int launch_simt_gemv_nb4(const SimtParams &p, int bits, int vec, const SimtGeometry &g, hipStream_t stream);
+int launch_simt_gemv_nb8(const SimtParams &p, int bits, int vec, const SimtGeometry &g, hipStream_t stream);
 
-int launch_simt_gemv(const SimtParams &p, int bits, int vec, int nb, int grid, hipStream_t stream) {
+int launch_simt_gemv(const SimtParams &p, int bits, int vec, int nb, const SimtGeometry &g, hipStream_t stream) {
     switch (nb) {
-        case 1: return launch_simt_gemv_nb1(p, bits, vec, grid, stream);
-        case 2: return launch_simt_gemv_nb2(p, bits, vec, grid, stream);
-        case 4: return launch_simt_gemv_nb4(p, bits, vec, grid, stream);
-        default: return launch_simt_gemv_nb8(p, bits, vec, grid, stream);
+        case 1: return launch_simt_gemv_nb1(p, bits, vec, g, stream);
+        case 2: return launch_simt_gemv_nb2(p, bits, vec, g, stream);
+        case 4: return launch_simt_gemv_nb4(p, bits, vec, g, stream);
+        default: return launch_simt_gemv_nb8(p, bits, vec, g, stream);
     }
 }
 

@@ -22,6 +22,37 @@ struct SimtParams {
     int n, m, k;
 };
 
+// launch geometry of simt_gemv_kernel (host side; see the kernel's header comment)
+struct SimtGeometry {
+    int grid, threads, dyn_lds, x_lds, split;
+};
+
+inline int simt_table_bytes(int bits, int vec) {  // = SimtCodec<bits, vec>::LDS_DWORDS * 4
+    const int idx = (vec == 1 && bits <= 6) ? 2 * bits : bits, edw = vec == 4 ? 2 : 1;
+    const int lmax = 15 - idx - (edw - 1), log2c = lmax < 5 ? lmax : 5;
+    return ((1 << idx) << log2c) * edw * 4;
+}
+
+inline SimtGeometry simt_gemv_geometry(int m, int n, int k, int bits, int vec, int num_cu) {
+    const int table = simt_table_bytes(bits, vec);
+    SimtGeometry g{};
+    g.x_lds = n == 1 && table + 2 * k <= 156 * 1024 && k % 8 == 0;
+    g.dyn_lds = g.x_lds ? 2 * k : 0;
+    const int lds = table + g.dyn_lds;
+    g.threads = lds <= 20 * 1024 ? 256 : lds <= 40 * 1024 ? 512 : 1024;
+    int per_cu = 160 * 1024 / (lds > 1024 ? lds : 1024);
+    if (per_cu > 1024 / g.threads) per_cu = 1024 / g.threads;  // 16 waves per CU resident (<= 128 VGPRs)
+    if (per_cu < 1) per_cu = 1;
+    // a row per wave (halves on alternate blocks) when two rows per wave would leave resident wave slots empty; it costs a
+    // sixth reduction step per row, which shows on long layers of short rows
+    const int nblk = (k + 1024 * vec - 1) / (1024 * vec);
+    g.split = nblk >= 2 && (m + 1) / 2 < num_cu * 16;
+    const int items = g.split ? m : (m + 1) / 2, wpg = g.threads / 64;
+    g.grid = (items + wpg - 1) / wpg;
+    if (g.grid > num_cu * per_cu) g.grid = num_cu * per_cu;
+    return g;
+}
+
 template <int BITS, int VEC>
 struct SimtCodec {
     static constexpr bool PAIR = (VEC == 1 && BITS <= 6);
@@ -49,6 +80,41 @@ struct SimtCodec {
                 lds[i] = (uint32_t)l16[e & ((1 << BITS) - 1)] | ((uint32_t)l16[e >> BITS] << 16);
             } else {
                 lds[i] = l16[e];
+            }
+        }
+    }
+
+    // same image, any workgroup size: 16-byte chunks (C >= 4 copies of a 4-byte entry, C >= 2 of an 8-byte one, are
+    // adjacent), eight table reads in flight per thread before the first LDS write
+    static constexpr int CHUNKS = LDS_DWORDS / 4;
+    static_assert(LOG2C + (EDW - 1) >= 2, "a 16-byte chunk holds copies of one entry");
+    static __device__ __forceinline__ u32x4 chunk(const void *tab, int c) {
+        const gptr<const uint16_t> l16 = as_global(static_cast<const uint16_t *>(tab));
+        const gptr<const uint32_t> l32 = as_global(static_cast<const uint32_t *>(tab));
+        const int e = (c * 4 / EDW) >> LOG2C;
+        if constexpr (VEC == 4) {
+            const uint32_t lo = l32[2 * e], hi = l32[2 * e + 1];
+            return u32x4{lo, hi, lo, hi};
+        } else {
+            uint32_t v;
+            if constexpr (VEC == 2) v = l32[e];
+            else if constexpr (PAIR) v = (uint32_t)l16[e & ((1 << BITS) - 1)] | ((uint32_t)l16[e >> BITS] << 16);
+            else v = l16[e];
+            return u32x4{v, v, v, v};
+        }
+    }
+    static __device__ __forceinline__ void build_chunks(uint32_t *lds, const void *tab, int tid, int nthreads) {
+        for (int c0 = tid; c0 < CHUNKS; c0 += nthreads * 8) {
+            u32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int c = c0 + j * nthreads;
+                v[j] = chunk(tab, c < CHUNKS ? c : CHUNKS - 1);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int c = c0 + j * nthreads;
+                if (c < CHUNKS) reinterpret_cast<u32x4 *>(lds)[c] = v[j];
             }
         }
     }
@@ -162,6 +228,142 @@ __global__ __launch_bounds__(1024) void simt_kernel(const SimtParams p) {
                     p.out[(long)b * p.m + row] = __builtin_bit_cast(uint16_t, hv);
                 }
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMV on the SIMT format, MI355X form.  The packed rows are tiny (k = 4096 at 3 bits per pair: 768 B), so the kernel is
+// a latency problem before it is a bandwidth problem: what counts is how many independent loads are in flight per CU.
+//   * one ROW PER WAVE when the row has >= 2 blocks (the two 32-lane halves take alternate blocks, one more xor step in
+//     the reduction); two rows per wave otherwise (vec_sz 4 with k = 4096: one block per row);
+//   * the first unit's packed words are requested BEFORE the codebook image is built, and every later unit's words while
+//     the previous unit is being decoded (register double buffer);
+//   * the workgroup size follows the LDS footprint (host: simt_gemv_geometry) so that small layers still spread over all
+//     CUs and big tables still have >= 16 waves behind them; the grid is persistent (several workgroups per CU, rows
+//     strided over waves): the image is built once per workgroup;
+//   * batch 1 stages x in LDS (dynamic, after the image); larger batches read it through L1.
+template <int BITS, int VEC, int NB, bool XL>
+__global__ __launch_bounds__(1024) void simt_gemv_kernel(const SimtParams p, const int split_rows) {
+    static_assert(!XL || NB == 1, "x is staged in LDS for batch 1 only");
+    using Cd = SimtCodec<BITS, VEC>;
+    __shared__ __attribute__((aligned(16))) uint32_t lut[Cd::LDS_DWORDS];
+    extern __shared__ __attribute__((aligned(16))) uint16_t xs_dyn[];
+    const int tid = threadIdx.x, lane = tid & 63, t = lane & 31, half = lane >> 5;
+    const int nthreads = blockDim.x, wpg = nthreads >> 6;
+    const uint32_t laneoff = (uint32_t)(t & (Cd::C - 1)) << (Cd::EDW == 2 ? 3 : 2);
+
+    const long row_words = (long)p.k * BITS / 32 / VEC;
+    const int nblk = (p.k + Cd::BLOCK - 1) / Cd::BLOCK;
+    const int nfull = p.k / Cd::BLOCK;
+    const int wtail = (p.k % Cd::BLOCK) / (32 * VEC);
+    const bool split = split_rows != 0;                // wave-uniform (host: only when the row has >= 2 blocks)
+    const int nrp = split ? p.m : (p.m + 1) / 2;       // wave-level work items
+    const int niter = split ? (nblk + 1) / 2 : nblk;   // units per item and half
+    const int gw = blockIdx.x * wpg + (tid >> 6), nw = gridDim.x * wpg;
+    const gptr<const uint32_t> q = as_global(p.q);
+
+    // unit (rp, i) of this half-wave: row, block, lane count; `false` when the half has nothing there
+    auto issue = [&](int rp, int i, uint32_t (&w)[BITS]) -> bool {
+        const int row = split ? rp : rp * 2 + half;
+        const int blk = split ? 2 * i + half : i;
+        const int W = blk < nfull ? 32 : wtail;
+        const bool ok = rp < nrp && row < p.m && blk < nblk && t < W;
+        if (ok) {
+            const gptr<const uint32_t> src = q + (long)row * row_words + (long)blk * BITS * 32 + t;
+#pragma unroll
+            for (int j = 0; j < BITS; j++) w[j] = __builtin_nontemporal_load(src + (long)W * j);
+        }
+        return ok;
+    };
+
+    uint32_t wa[BITS], wb[BITS];
+    bool oka = issue(gw, 0, wa);
+    if constexpr (XL) {
+        const int total = p.n * p.k;  // multiple of 8 halves
+        for (int i0 = tid * 8; i0 < total; i0 += nthreads * 32) {
+            u32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int i = i0 + j * nthreads * 8;
+                v[j] = *(gptr<const u32x4>)as_global(p.x + (i < total ? i : 0));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int i = i0 + j * nthreads * 8;
+                if (i < total) *reinterpret_cast<u32x4 *>(xs_dyn + i) = v[j];
+            }
+        }
+    }
+    Cd::build_chunks(lut, p.lut, tid, nthreads);
+    __syncthreads();
+
+    const gptr<const uint16_t> xg = as_global(p.x);
+    auto unit = [&](int i, const uint32_t (&w)[BITS], float (&acc)[NB]) {
+        const int blk = split ? 2 * i + half : i;
+        const int W = blk < nfull ? 32 : wtail;
+        const int e0 = blk * Cd::BLOCK + 8 * t;  // 32-bit element offsets: 64-bit ones cost a register pair per x read
+        static_for<0, Cd::NGRP>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            uint32_t h[4];
+            Cd::template group<g>(lut, laneoff, w, h);
+            const int elem = e0 + g * 8 * W;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const int bb = b < p.n ? b : p.n - 1;
+                u32x4 xv;
+                if constexpr (XL) xv = *reinterpret_cast<const u32x4 *>(xs_dyn + elem);
+                else xv = *(gptr<const u32x4>)(xg + (bb * p.k + elem));
+                acc[b] = fdot2(h[0], xv.x, acc[b]);
+                acc[b] = fdot2(h[1], xv.y, acc[b]);
+                acc[b] = fdot2(h[2], xv.z, acc[b]);
+                acc[b] = fdot2(h[3], xv.w, acc[b]);
+            }
+            // vec_sz 4 has 16 groups per unit: left alone the scheduler hoists every x read (64 registers) and spills
+            if constexpr (Cd::NGRP > 8 && (g & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    // flattened (item, unit) sequence, two units per trip so that the double buffer needs no register copies
+    int rp = gw, i = 0;
+    float acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] = 0.f;
+    auto finish_row = [&]() {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            float v = acc[b];
+            v = wave_xor_add(v, 1);
+            v = wave_xor_add(v, 2);
+            v = wave_xor_add(v, 4);
+            v = wave_xor_add(v, 8);
+            v = wave_xor_add(v, 16);
+            if (split) v = wave_xor_add(v, 32);
+            const int row = split ? rp : rp * 2 + half;
+            if (t == 0 && (!split || half == 0) && row < p.m && b < p.n)
+                p.out[(long)b * p.m + row] = __builtin_bit_cast(uint16_t, (_Float16)v);
+            acc[b] = 0.f;
+        }
+    };
+    while (rp < nrp) {  // wave-uniform
+        {
+            int rn = rp, in = i + 1;
+            if (in >= niter) { rn = rp + nw; in = 0; }
+            const bool okb = issue(rn, in, wb);
+            if (oka) unit(i, wa, acc);
+            if (in == 0) finish_row();
+            rp = rn; i = in;
+            oka = okb;  // (name reused below: wb now holds the current unit)
+        }
+        if (rp >= nrp) break;
+        {
+            int rn = rp, in = i + 1;
+            if (in >= niter) { rn = rp + nw; in = 0; }
+            const bool okn = issue(rn, in, wa);
+            if (oka) unit(i, wb, acc);
+            if (in == 0) finish_row();
+            rp = rn; i = in;
+            oka = okn;
         }
     }
 }

@@ -468,7 +468,11 @@ __global__ __launch_bounds__(kChainThreads) void tc_chain_kernel(const TcMultiPa
         QPAL_CSTAMP(2);
 
         // ---------------------------------------------------------------- B: the dependency
+#ifdef QPAL_TEST_NODEP  // timing experiment only (valid with static activations): what does a chain cost with NO dependency protocol?
+        if (false) {
+#else
         if (ph > 0 && wave == 0) {
+#endif
             const unsigned done = seq0 + (unsigned)ph;  // phases whose arrivals must be in
             unsigned need = 0;
             if (lane < kChainShards) need = ((gridDim.x + (kChainShards - 1) - lane) / kChainShards) * done;
@@ -497,7 +501,11 @@ __global__ __launch_bounds__(kChainThreads) void tc_chain_kernel(const TcMultiPa
                     if (i < total) v = __builtin_bit_cast(float, ld_agent(src + i)) * p.x_f32_scale;
                     xs[i] = __builtin_bit_cast(uint16_t, (_Float16)v);
                 }
+#ifdef QPAL_TEST_FRESHX  // timing experiment: every phase stages x with agent-scope loads (the round trip an embedded-flag poll would pay)
+            } else if (true) {
+#else
             } else if (p.x_fresh) {
+#endif
                 const unsigned *src = reinterpret_cast<const unsigned *>(p.x);
                 for (int i = tid; i < (total + 32) / 2; i += kChainThreads)
                     reinterpret_cast<uint32_t *>(xs)[i] = i < total / 2 ? ld_agent(src + i) : 0u;
@@ -568,6 +576,7 @@ __global__ __launch_bounds__(kChainThreads) void tc_chain_kernel(const TcMultiPa
         }
         // Arrival: every wave waits for its own stores (but not for the packed words it has already requested for the
         // next phase: they are younger, and memory operations complete in issue order), the last of the 8 signals.
+#ifndef QPAL_TEST_NODEP
         if (tid < (32 << log2_rpw) || mp.zero_chunks > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
             const unsigned old = __hip_atomic_fetch_add(&wave_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -575,6 +584,7 @@ __global__ __launch_bounds__(kChainThreads) void tc_chain_kernel(const TcMultiPa
                 __hip_atomic_fetch_add(as_global(&ws->shard[blockIdx.x & (kChainShards - 1)][0]), 1u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
         }
+#endif
         QPAL_CSTAMP(7);
     }
     if (blockIdx.x == 0 && tid == 0) st_agent(&ws->epoch, seq0 + (unsigned)nphases);

@@ -142,6 +142,29 @@ def test_simt_golden(qp, oracle, vec, bits):
         _check_gemv(y.float().cpu().numpy().reshape(n, m), W, x.reshape(n, k), oracle, fp16_out=True)
 
 
+@pytest.mark.parametrize("vec,bits,m,k", [(1, 2, 8199, 2560), (1, 7, 8199, 2560), (2, 3, 8199, 2560), (2, 9, 8199, 6144),
+                                          (4, 6, 8199, 5120), (4, 12, 8199, 4096), (2, 5, 1024, 14336), (4, 8, 4096, 14336),
+                                          (1, 4, 1023, 4096)])
+def test_simt_gemv_geometries(qp, oracle, vec, bits, m, k):
+    """Every launch geometry of the SIMT GEMV (csrc/simt_kernels.h simt_gemv_geometry): two rows per wave with several
+    blocks per row and rows strided over a persistent grid (m > 2 * resident waves), a row per wave with the halves on
+    alternate blocks (small m), odd row counts, trailing partial blocks, every workgroup size (table 0.5 .. 128 KiB)."""
+    rng = np.random.default_rng(bits * 7 + vec + m)
+    idx = torch.from_numpy(rng.integers(0, 1 << bits, size=(m, k // vec), dtype=np.int64))
+    lut = rng.standard_normal((1 << bits, vec)).astype(np.float16)
+    q = qp.packers.pack_qweight_sq_simt(idx, bits) if vec == 1 else qp.packers.pack_qweight_vq_simt(idx, bits, vec)
+    assert np.array_equal(oracle.simt_indices(q.numpy().view(np.uint32), m, k, bits, vec), idx.numpy())
+    W = lut[idx.numpy()].reshape(m, k)
+    qd, ld = q.cuda(), _cuda(lut)
+    for n in (1, 2):
+        x = rng.standard_normal((n, 1, k)).astype(np.float16)
+        if vec == 1:
+            y = qp.ops.get_op("sq_pack_gemm_simt")(_cuda(x), qd, ld, bits)
+        else:
+            y = qp.ops.get_op(f"vq_pack_gemm_simt_{n}_{vec}_{bits}")(_cuda(x), qd, ld)
+        _check_gemv(y.float().cpu().numpy().reshape(n, m), W, x.reshape(n, k), oracle, fp16_out=True)
+
+
 @pytest.mark.parametrize("vec,bits", [(1, 3), (1, 4), (1, 8), (2, 5), (2, 8), (2, 12)])
 def test_tc_to_simt_golden(qp, vec, bits):
     g = _g("simt.npz")
