@@ -337,55 +337,108 @@ __global__ __launch_bounds__(256) void had_mfma_kernel(HadParams p) {
         });
 }
 
-// Second half of the two-launch K > 1 path: out[j][c] <- fp16(fp16(sum_i hadK[j][i] t[i][c]) * post [* sv]) IN PLACE, t = the
-// fp16 segment transforms the first launch left in `out`.  One wave per 16-column tile (it reads and writes only its
-// own columns, so the update is race-free across waves and workgroups); K <= 32.
-__global__ __launch_bounds__(256) void hadk_mix_kernel(HadParams p) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = lane >> 4, c16 = lane & 15;
+// K > 1 in ONE launch without a single-workgroup bottleneck: the two factors commute, so workgroup (row, block, j) first
+// forms row j of the hadK product, m[c] = sum_i hadK[j][i] a[i][c] (it reads the whole block: 2 .. 8 bytes per element from
+// L2, coalesced, every load of a thread in flight at once — K workgroups read what one workgroup read before), then runs
+// WHT_P on its own P values in LDS and stores segment j.  fp32 until the one final rounding (the reference's fp16
+// intermediate t is not formed: round_mid callers get a result at least as close to the exact transform).
+// The 14336-vector with SwiGLU: two launches (4.9 + 4.9 us inside a token's graph) -> one.
+template <int NT, int MODE, bool SU>
+__global__ __launch_bounds__(NT) void had_mixfirst_kernel(HadParams p) {
+    extern __shared__ float buf[];  // [parts][P] partial rows, then pad(P) floats for the butterflies
+    const int tid = threadIdx.x;
     const int P = 1 << p.logP;
-    const int tiles = P >> 4;                      // column tiles per block
-    const int tile = blockIdx.x * 4 + wave;        // over rows * blocks * tiles
-    if (tile >= p.rows * (p.n / p.hd) * tiles) return;
-    const int ct = tile % tiles, bidx = tile / tiles;
-    uint16_t *blk = p.out + (long)bidx * p.hd;     // rows and blocks are contiguous: [rows][n / hd][hd]
-    const int c = (ct << 4) + c16;
-    uint16_t araw[2][8], traw[8];
+    const int bpr = p.n / p.hd;
+    int b = blockIdx.x;
+    const int j = b % p.K;
+    b /= p.K;
+    const int row = b / bpr, blk = b - row * bpr;
+    const int col0 = blk * p.hd;
+    const int parts = NT >> p.logP;  // host: P <= NT, both powers of two
+    // P >= 64: the row part is wave-uniform, so the hadK entries are scalar loads and every address is a uniform base plus
+    // one per-lane 32-bit offset
+    const int c = tid & (P - 1), rp = __builtin_amdgcn_readfirstlane(tid >> p.logP);
+    float acc = 0.f;
+    // Raw loads first, arithmetic after; input mode and sign flip are template parameters: a run-time branch anywhere in
+    // the batch makes the compiler wait for every load issued before it (measured: 13 us for the 14336-vector instead of
+    // one round trip).  Index clamped and weight masked past K.  The workgroup is instruction-bound (14 elements per thread,
+    // four waves per SIMD): the SwiGLU uses the hardware reciprocal (1 ulp of fp32, then rounded to fp16 as the reference's
+    // fp16 silu is) instead of a full division.
+    const gptr<const uint16_t> hk = as_global(p.hadk) + j * p.K;
+    for (int i0 = rp; i0 < p.K; i0 += 16 * parts) {
+        float v[16];
+        uint16_t sraw[16], kraw[16];
+        uint32_t at[16];  // element offsets inside the row (n < 2^31: checked by the C-ABI)
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const int i = (q << 3) + e;
-        traw[e] = blk[(i < p.K ? i : p.K - 1) * P + c];
-    }
-#pragma unroll
-    for (int jt = 0; jt < 2; jt++) {
-        const int ja = (jt << 4) + c16;
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int i = (q << 3) + e;
-            araw[jt][e] = p.hadk[(ja < p.K ? ja : p.K - 1) * p.K + (i < p.K ? i : p.K - 1)];
+        for (int u = 0; u < 16; u++) {
+            const int i = i0 + u * parts, ic = i < p.K ? i : p.K - 1;
+            at[u] = (uint32_t)(col0 + ic * P) + (uint32_t)c;
+            kraw[u] = hk[ic];
         }
-    }
-    half8_t b;
+        if constexpr (SU) {
+            const gptr<const uint16_t> su = as_global(p.su);
 #pragma unroll
-    for (int e = 0; e < 8; e++) b[e] = (q << 3) + e < p.K ? __builtin_bit_cast(_Float16, traw[e]) : (_Float16)0.f;
-    const int col0 = (bidx % (p.n / p.hd)) * p.hd;
+            for (int u = 0; u < 16; u++) sraw[u] = su[at[u]];
+        }
+        if constexpr (MODE == QPAL_IN_SWIGLU_F32) {
+            const gptr<const float> src = as_global(static_cast<const float *>(p.in)) + (long)row * 2 * p.n;
+            const gptr<const float> srg = src + p.n;
+            float up[16], gate[16];
 #pragma unroll
-    for (int jt = 0; jt < 2; jt++) {
-        half8_t a;
+            for (int u = 0; u < 16; u++) up[u] = src[at[u]], gate[u] = srg[at[u]];
 #pragma unroll
-        for (int e = 0; e < 8; e++)
-            a[e] = ((q << 3) + e < p.K && (jt << 4) + c16 < p.K) ? __builtin_bit_cast(_Float16, araw[jt][e]) : (_Float16)0.f;
-        float4_t acc{0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int j = (jt << 4) + (q << 2) + r;
-            if (j < p.K) {
-                float u = round_f16(acc[r]) * p.post_scale;
-                if (p.sv) u = round_f16(u) * h2f(p.sv[col0 + j * P + c]);
-                blk[j * P + c] = f2h(u);
+            for (int u = 0; u < 16; u++) {
+                const float uu = round_f16(up[u]), gt = round_f16(gate[u]);
+                const float sg = gt * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gt * -1.44269504f));
+                v[u] = round_f16(round_f16(sg) * uu);
             }
+        } else if constexpr (MODE == QPAL_IN_F32) {
+            const gptr<const float> src = as_global(static_cast<const float *>(p.in)) + (long)row * p.n;
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = src[at[u]];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = round_f16(v[u]);
+        } else {
+            const gptr<const uint16_t> src = as_global(static_cast<const uint16_t *>(p.in)) + (long)row * p.n;
+            uint16_t raw[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) raw[u] = src[at[u]];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = h2f(raw[u]);
         }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int i = i0 + u * parts;
+            if constexpr (SU) v[u] = round_f16(v[u] * h2f(sraw[u]));
+            acc += (i < p.K ? h2f(kraw[u]) : 0.f) * v[u];
+        }
+    }
+    float *m = buf + parts * P;
+    if (parts > 1) {
+        buf[rp * P + c] = acc;
+        __syncthreads();
+        if (tid < P) {
+            float t = 0.f;
+            for (int q = 0; q < parts; q++) t += buf[q * P + tid];
+            m[pad(tid)] = t;
+        }
+    } else {
+        m[pad(c)] = acc;
+    }
+    __syncthreads();
+    HadParams s = p;  // the segment as a K = 1 transform of its own (pre_scale stays the block's hd^-1/2)
+    s.hd = P;
+    s.K = 1;
+    int b0 = 0;
+    for (int ps = 0; ps < p.npass; ps++) {
+        const int r = p.r[ps];
+        if (ps == p.npass - 1) {
+            had_pass_r<false, true, NT>(r, s, m, b0, row, col0 + j * P, tid);
+        } else {
+            had_pass_r<false, false, NT>(r, s, m, b0, row, col0 + j * P, tid);
+            __syncthreads();
+        }
+        b0 += r;
     }
 }
 
@@ -409,22 +462,27 @@ void plan_passes(HadParams &p) {
 }
 
 int launch_hadamard(const HadParams &p, hipStream_t stream) {
-    if (p.K > 1 && p.K <= 32 && p.round_mid && p.logP >= 6 && p.hd > 4096) {
-        // Two launches instead of one workgroup: (1) every 2^p-segment as its own K = 1 transform on its own compute
-        // unit (scaled by the block's hd^-1/2, fp16 = the reference's intermediate), (2) hadK across the segments, in
-        // place.  The 14336-vector with SwiGLU: 12.4 us -> 2 short launches.  (One launch with the last-arriving
-        // workgroup doing step 2 needs device-scope fences: measured 18.7 us.)
+    if (p.K > 1 && p.K <= 32 && p.round_mid && p.logP >= 6 && p.logP <= 10 && p.hd > 4096) {
+        // One launch, K workgroups per block (had_mixfirst_kernel).  History: one workgroup for the whole 14336-vector with
+        // SwiGLU 12.4 us; segment transforms + in-place hadK mix as two launches 2 x 4.9 us; a last-arriving workgroup
+        // doing the mix behind device-scope fences 18.7 us.
         HadParams a = p;
-        a.hd = 1 << p.logP;
-        a.K = 1;
-        a.post_scale = 1.0f;
-        a.sv = nullptr;
-        a.hadk = nullptr;
-        plan_passes(a);
-        int rc = launch_hadamard(a, stream);
-        if (rc) return rc;
-        const int tiles = p.rows * (p.n / p.hd) * (a.hd >> 4);
-        hipLaunchKernelGGL(hadk_mix_kernel, dim3((tiles + 3) / 4), dim3(256), 0, stream, p);
+        HadParams seg = p;
+        seg.hd = 1 << p.logP;
+        plan_passes(seg);
+        a.npass = seg.npass;
+        for (int i = 0; i < 4; i++) a.r[i] = seg.r[i];
+        constexpr int NT = 1024;
+        const int P = 1 << p.logP, parts = NT / P;
+        const size_t lds = sizeof(float) * (size_t)(parts * P + P + (P >> 5) + 1);
+        const dim3 grid(p.rows * (p.n / p.hd) * p.K);
+#define QPAL_MIXFIRST(M_)                                                                                          \
+    if (p.in_mode == M_) {                                                                                         \
+        if (p.su) hipLaunchKernelGGL((had_mixfirst_kernel<NT, M_, true>), grid, dim3(NT), lds, stream, a);         \
+        else hipLaunchKernelGGL((had_mixfirst_kernel<NT, M_, false>), grid, dim3(NT), lds, stream, a);             \
+    }
+        QPAL_MIXFIRST(QPAL_IN_F16) QPAL_MIXFIRST(QPAL_IN_F32) QPAL_MIXFIRST(QPAL_IN_SWIGLU_F32)
+#undef QPAL_MIXFIRST
         return (int)hipGetLastError();
     }
     if (p.K == 1 && p.in_mode == QPAL_IN_F16 && (p.hd == 1024 || p.hd == 2048 || p.hd == 4096)) {  // 8192: the butterflies win (measured)

@@ -588,44 +588,21 @@ __global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const u
                 if (ROT && p.x_rot) {
                   if constexpr (ROT) {
                     // Incoherence rotation fused into the staging (wht64.h: Walsh-Hadamard transform on the matrix pipe).
-                    auto store_row = [&](uint16_t *dst) {
-                        return [=](int, int, int i, float v) {
-                            dst[i] = __builtin_bit_cast(uint16_t, (_Float16)((float)(_Float16)v * p.x_post));
-                        };
-                    };
                     wht_float4 *d1buf = reinterpret_cast<wht_float4 *>(xs + ((total + 32 + 7) & ~7));  // <= 16 KiB
-                    // RMSNorm fused into the rotation's input (decoder-block fusion): the sum of squares first (x is 8-16 KiB,
-                    // L2-resident: a second read beats a launch of its own), then every loaded element is scaled in fp32
-                    float inv_rms = 1.0f;
-                    if (p.x_rms_eps > 0.f) {
-                        float ss = 0.f;
-                        for (int i = tid * 4; i < total; i += NT * 4) {
-                            float f[4];
-                            if (p.x_src_f32) {
-                                const float4_t v = *reinterpret_cast<const float4_t *>(reinterpret_cast<const float *>(p.x) + i);
-                                f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
-                            } else {
-                                const u32x2 v = *reinterpret_cast<const u32x2 *>(p.x + i);
-                                const h2_t a = __builtin_bit_cast(h2_t, v.x), b = __builtin_bit_cast(h2_t, v.y);
-                                f[0] = (float)a[0]; f[1] = (float)a[1]; f[2] = (float)b[0]; f[3] = (float)b[1];
-                            }
-                            ss += f[0] * f[0] + f[1] * f[1] + f[2] * f[2] + f[3] * f[3];
-                        }
-#pragma unroll
-                        for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
-                        float *part = reinterpret_cast<float *>(d1buf + 4 * 4 * 64);
-                        if (lane == 0) part[wave] = ss;
-                        __syncthreads();
-                        float tot = 0.f;
-#pragma unroll
-                        for (int wv = 0; wv < W; wv++) tot += part[wv];
-                        inv_rms = __builtin_amdgcn_rsqf(tot / (float)total + p.x_rms_eps);
-                    }
+                    // RMSNorm fused into the rotation (decoder-block fusion).  The transform is linear, so the norm's scalar
+                    // 1/rms is applied AFTER it: stage 1 rotates x * w * 2^-6 (the power of two keeps fp16 clear of overflow
+                    // on residual-stream outliers; the rounding is relative, as on the normalised value) while the same lanes
+                    // sum the squares of what they load; the sums meet at the barrier the transform has anyway.  x is read
+                    // once and no wave waits for the norm before the matrix pipe starts.
+                    const bool rms = p.x_rms_eps > 0.f;
+                    constexpr float kRmsPre = 0.015625f;
+                    float ss = 0.f;
+                    float *part = reinterpret_cast<float *>(d1buf + 4 * 4 * 64);
                     auto load_row = [&](const uint16_t *xrow) {
-                        return [=](int t, int kc) {
+                        return [=, &ss](int t, int kc) {
                             const int off = (16 * t + (lane & 15)) * 64 + 32 * kc + 8 * (lane >> 4);
                             wht_half8 h;
-                            if (p.x_src_f32 || p.x_rms_eps > 0.f) {
+                            if (p.x_src_f32 || rms) {
                                 float f[8];
                                 if (p.x_src_f32) {
                                     const float *xf = reinterpret_cast<const float *>(xrow) + off;
@@ -639,8 +616,12 @@ __global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const u
                                 }
                                 wht_half8 wgt;
                                 if (p.x_rms_w) wgt = *reinterpret_cast<const wht_half8 *>(p.x_rms_w + off);
+                                const float pre = rms ? kRmsPre : 1.0f;
 #pragma unroll
-                                for (int e = 0; e < 8; e++) h[e] = (_Float16)(f[e] * inv_rms * (p.x_rms_w ? (float)wgt[e] : 1.0f));
+                                for (int e = 0; e < 8; e++) {
+                                    ss += f[e] * f[e];
+                                    h[e] = (_Float16)(f[e] * pre * (p.x_rms_w ? (float)wgt[e] : 1.0f));
+                                }
                             } else {
                                 h = *reinterpret_cast<const wht_half8 *>(xrow + off);
                             }
@@ -655,12 +636,28 @@ __global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const u
                     // launch; x * su staged in LDS first, two more barriers.)
                     if (p.x_rot == 4) wht64_wg_stage1<4>(wave, lane, d1buf, load_row(p.x));
                     else wht64_wg_stage1<2>(wave, lane, d1buf, load_row(p.x));
+                    if (rms && wave < p.x_rot) {
+#pragma unroll
+                        for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+                        if (lane == 0) part[wave] = ss;
+                    }
                     if (p.tab != cur_tab) {
                         if (wave >= p.x_rot) C1::build(lut, p.tab, tid - 64 * p.x_rot, 1024 - 64 * p.x_rot);
                         cur_tab = p.tab;
                     }
                     if (tid < 32) xs[total + tid] = 0;
                     __syncthreads();
+                    float post = 1.0f;
+                    if (rms) {
+                        float tot = part[0] + part[1];
+                        if (p.x_rot == 4) tot += part[2] + part[3];
+                        post = __builtin_amdgcn_rsqf(tot / (float)total + p.x_rms_eps) * (1.0f / kRmsPre);
+                    }
+                    auto store_row = [&](uint16_t *dst) {
+                        return [=](int, int, int i, float v) {
+                            dst[i] = __builtin_bit_cast(uint16_t, (_Float16)((float)(_Float16)(v * post) * p.x_post));
+                        };
+                    };
                     if (p.x_rot == 4) wht64_wg_stage2<4>(wave, lane, p.x_pre, d1buf, store_row(xs));
                     else wht64_wg_stage2<2>(wave, lane, p.x_pre, d1buf, store_row(xs));
                   }

@@ -199,8 +199,17 @@ def test_rotate_vs_oracle(qp, rows, n, hd, round_mid):
         t = oi.f16(oi.wht(xs.reshape(rows, n // hd, K, hd // K)) * float(hd) ** -0.5)
         extra = np.broadcast_to(_ulp16(np.abs(t).max(axis=-2, keepdims=True)), t.shape).reshape(rows, n) / 64
         got = y.cpu().numpy().astype(np.float64)
-        assert np.all(np.abs(got - want) <= (_ulp16(want) + extra) * 1.0001)
-        assert (np.abs(got - want) > _ulp16(want) * 1.0001).mean() < 1e-3  # and it is rare
+        if hd > 4096 and K <= 32:
+            # large blocks take the one-launch mix-first kernel (csrc/hadamard.hip had_mixfirst_kernel): hadK before the
+            # butterflies, fp32 throughout, ONE rounding — the reference's fp16 intermediate t is never formed.  The result
+            # is the correctly rounded exact transform (to an ulp), and it stays inside the reference pipeline's own
+            # rounding noise around the reference-rounded value: K terms, each off by at most half an ulp of t.
+            exact = oi.f16(oi.had_blocks(xs, hd, hT.numpy().astype(np.float64), round_mid=False)) / 64
+            _assert_ulp(got, exact)
+            assert np.all(np.abs(got - want) <= (1.5 * _ulp16(want) + 0.5 * K * extra) * 1.0001)
+        else:
+            assert np.all(np.abs(got - want) <= (_ulp16(want) + extra) * 1.0001)
+            assert (np.abs(got - want) > _ulp16(want) * 1.0001).mean() < 1e-3  # and it is rare
     else:
         _assert_ulp(y.cpu().numpy(), want)
 
