@@ -239,6 +239,14 @@ int qpal_rope_kv(const float *q, const float *k, const float *v, void *q_out_f16
 int qpal_attn_decode(const void *q_f16, const void *kcache_f16, const void *vcache_f16, void *out_f16, const long *pos,
                      int nq, int nkv, int hd, long max_len, float scale, void *stream);
 
+/* The two launches above as one (what a decode step runs): rotary embedding of the new token's q / k, k and v appended to the
+ * cache at *pos, attention over positions 0 .. *pos, fp16 out [nq][hd].  q / k / v fp32 as for qpal_rope_kv.  hd in {64, 128,
+ * 256}; max_len % 4 == 0, up to ~38 k positions.  The new row is read from on-chip memory by every head of its group: nothing
+ * this launch reads was written by it.                                                                                    */
+int qpal_attn_rope_decode(const float *q, const float *k, const float *v, void *kcache_f16, void *vcache_f16, void *out_f16,
+                          const long *pos, const float *inv_freq, int nq, int nkv, int hd, long max_len, float scale,
+                          void *stream);
+
 /* 1 if the GEMV entry points can apply the rotation themselves (x_had): k in {2048, 4096} at batch 1 (the
  * decode case); 0 otherwise (then call qpal_hadamard first). */
 int qpal_can_fuse_rotation(int n, int k);

@@ -103,6 +103,7 @@ def main(argv=None):
     ap.add_argument("--layers", type=int, default=0)
     ap.add_argument("--context", type=int, default=1024, help="static KV-cache length attended over")
     ap.add_argument("--tokens", type=int, default=64)
+    ap.add_argument("--start-pos", type=int, default=8, help="position of the first timed token (the cache below it is attended over)")
     ap.add_argument("--vocab", type=int, default=128256)
     ap.add_argument("--no-fused", action="store_true", help="skip the fused-glue step (third figure)")
     ap.add_argument("--no-modular", action="store_true", help="time the fused-glue step only (profiling)")
@@ -173,15 +174,15 @@ def main(argv=None):
             for i in range(args.tokens):
                 if glue:                       # the next step consumes the sampled token at the next position
                     tok.copy_(out_tok)
-                    pos.fill_(min(args.context - 1, 8 + i))
+                    pos.fill_(min(args.context - 1, args.start_pos + i))
                 g.replay()
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / args.tokens
 
     # ---- fused glue (MI355X decoder block): the residual stream stays fp32; RMSNorm + sign flip + Hadamard run inside the
     # q|k|v and up|gate launches (x_rms / x_rot on the fp32 stream), o_proj and down_proj ADD into the stream (accumulate),
-    # rotary embedding + KV-cache write are one launch (qpal_rope_kv), attention over the cache one launch (qpal_attn_decode):
-    # 8 launches per layer instead of ~41.
+    # rotary embedding + KV-cache append + attention over the cache are one launch (qpal_attn_rope_decode), the SwiGLU rotation
+    # one: 6 launches per layer instead of ~41.
     nat = qp._native
     h32 = torch.zeros(1, H, dtype=torch.float32, device=dev)
     nq, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
@@ -199,15 +200,11 @@ def main(argv=None):
                       x_rot=(att.SU_qkv, 1.0 / att.scale), x_rms=(eps, layer.input_layernorm.weight))
         parts = dict(zip([b[0] for b in blocks], qkv32.split([b[1] for b in blocks], dim=1)))
         with torch.cuda.device(dev):
-            rc = nat.lib().qpal_rope_kv(parts["q"].data_ptr(), parts["k"].data_ptr(), parts["v"].data_ptr(), q16.data_ptr(),
-                                        cache.k[idx].data_ptr(), cache.v[idx].data_ptr(), pos.data_ptr(), inv_freq.data_ptr(),
-                                        nq, nkv, head_dim, args.context, torch.cuda.current_stream(dev).cuda_stream)
-        nat.check(rc, "qpal_rope_kv")
-        with torch.cuda.device(dev):
-            rc = nat.lib().qpal_attn_decode(q16.data_ptr(), cache.k[idx].data_ptr(), cache.v[idx].data_ptr(), a16.data_ptr(),
-                                            pos.data_ptr(), nq, nkv, head_dim, args.context, 1.0 / math.sqrt(head_dim),
-                                            torch.cuda.current_stream(dev).cuda_stream)
-        nat.check(rc, "qpal_attn_decode")
+            rc = nat.lib().qpal_attn_rope_decode(parts["q"].data_ptr(), parts["k"].data_ptr(), parts["v"].data_ptr(),
+                                                 cache.k[idx].data_ptr(), cache.v[idx].data_ptr(), a16.data_ptr(), pos.data_ptr(),
+                                                 inv_freq.data_ptr(), nq, nkv, head_dim, args.context, 1.0 / math.sqrt(head_dim),
+                                                 torch.cuda.current_stream(dev).cuda_stream)
+        nat.check(rc, "qpal_attn_rope_decode")
         qp.multi_gemv([att.o_proj], a16, outs=[h32], outs_zeroed=True, wscales=[att.Wscale_o], oscale=att.scale,
                       x_rot=(att.SU_o, 1.0 / att.scale), accumulate=True)
         inter = mlp.intermediate_size
@@ -252,7 +249,7 @@ def main(argv=None):
             t0 = time.perf_counter()
             for i in range(args.tokens):
                 tok.copy_(out_tok)
-                pos.fill_(min(args.context - 1, 8 + i))
+                pos.fill_(min(args.context - 1, args.start_pos + i))
                 g.replay()
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / args.tokens

@@ -63,6 +63,7 @@ _SIGNATURES = {
     "qpal_chain_launch": [_P, _P, _P, _P, _P],
     "qpal_rope_kv": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_long, _P],
     "qpal_attn_decode": [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_long, _F, _P],
+    "qpal_attn_rope_decode": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_long, _F, _P],
     "qpal_peer_gather": [_P, ctypes.c_long, _I, ctypes.POINTER(_P), ctypes.POINTER(_P), _I, _I, _P],
 }
 

@@ -68,6 +68,46 @@ def test_rope_kv_and_attn_decode_match_torch(qp, nq, nkv, hd, ctx, pos):
     assert torch.allclose(out.view(nq, hd).float(), ref.view(nq, hd), atol=2e-3, rtol=2e-3)
 
 
+@pytest.mark.parametrize("nq,nkv,hd,ctx,pos", [(32, 8, 128, 256, 17), (8, 8, 64, 64, 0), (64, 8, 128, 4096, 4095), (16, 4, 256, 512, 100),
+                                                (32, 8, 128, 1024, 1), (32, 8, 128, 2048, 1300)])
+def test_attn_rope_decode_one_launch_matches_torch(qp, nq, nkv, hd, ctx, pos):
+    """qpal_attn_rope_decode = rope + cache append + attention in one launch: equals the two-launch pair's math (torch
+    reference as above), leaves the cache exactly as qpal_rope_kv would, and does not depend on the cache row it writes."""
+    dev = torch.device("cuda", 0)
+    nat = qp._native
+    gen = torch.Generator(device=dev).manual_seed(nq * 7 + pos)
+    q32 = torch.randn(nq * hd, device=dev, generator=gen)
+    k32 = torch.randn(nkv * hd, device=dev, generator=gen)
+    v32 = torch.randn(nkv * hd, device=dev, generator=gen)
+    kc = (torch.randn(nkv, ctx, hd, device=dev, generator=gen) * 0.5).half()
+    vc = (torch.randn(nkv, ctx, hd, device=dev, generator=gen) * 0.5).half()
+    kc[:, pos] = float("nan")  # whatever is in the cache at the new position must not matter
+    vc[:, pos] = float("nan")
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    inv_freq = 1.0 / (500000.0 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
+    pos_t = torch.tensor([pos], dtype=torch.long, device=dev)
+    out = torch.empty(nq * hd, dtype=torch.float16, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    nat.check(nat.lib().qpal_attn_rope_decode(q32.data_ptr(), k32.data_ptr(), v32.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(),
+                                              pos_t.data_ptr(), inv_freq.data_ptr(), nq, nkv, hd, ctx, 1.0 / math.sqrt(hd), stream),
+              "qpal_attn_rope_decode")
+    ang = pos_t.float()[:, None] * inv_freq[None, :]
+    emb = torch.cat((ang, ang), dim=-1)
+    cos, sin = emb.cos().half(), emb.sin().half()
+    qh, kh = q32.half().view(nq, hd), k32.half().view(nkv, hd)
+    q_ref = qh * cos + _rotate_half(qh) * sin
+    kc_ref[:, pos] = kh * cos + _rotate_half(kh) * sin
+    vc_ref[:, pos] = v32.half().view(nkv, hd)
+    torch.cuda.synchronize()
+    assert torch.allclose(kc.float(), kc_ref.float(), atol=4e-3, rtol=2e-3) and torch.equal(vc, vc_ref)
+    qf = q_ref.view(1, nq, 1, hd).float()
+    kf = kc_ref[:, : pos + 1].float().repeat_interleave(nq // nkv, dim=0)[None]
+    vf = vc_ref[:, : pos + 1].float().repeat_interleave(nq // nkv, dim=0)[None]
+    ref = torch.softmax(qf @ kf.transpose(-1, -2) / math.sqrt(hd), dim=-1) @ vf
+    # q / k rotations differ from torch's by <= 1 fp16 ulp of cos / sin (fp32 sincos here): a few 1e-3 on a score of O(1)
+    assert torch.allclose(out.view(nq, hd).float(), ref.view(nq, hd), atol=4e-3, rtol=4e-3)
+
+
 @pytest.mark.parametrize("qstr", ["tcomb_6_7_0.5_none_0.9", "ldlq_2_8_none_1.0"])
 def test_rmsnorm_fp32_stream_and_accumulate_in_the_gemv_launch(qp, qstr):
     """multi_gemv(..., x = fp32 residual stream, x_rot, x_rms) == rotate(rmsnorm(x).half()) then GEMV; accumulate adds into out."""
