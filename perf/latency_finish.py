@@ -7,9 +7,8 @@ The reference's fusion-aware MSQ solver models a decoded token as
 (solve_lat_const.py:113-123; `lat_coeff_dict['constant'].item()`, loaded by lat_coeff_routine, l.219-221, from
 assets/{model_key}_latency_coeffs_{nodename}.pt).  `constant` is everything of a token that is not a quantized linear.  Here it is
 MEASURED with perf/decode_llama.py (whole decode step of a Llama-3.1-8B-shaped model under one HIP graph, context 1024):
-    constant = ms_whole_step - 32 * sum of the table's unfused q,k,v,o,g,u,d entries of the quantizer that run used
-so that the solver's formula reproduces the measured step for that model.  On MI355X it is dominated by ~1700 small torch
-launches of glue (RMSNorm, rotary embedding, cache update, SDPA, residuals) that the reference fuses with torch.compile.
+    constant = ms_fused_glue - 32 * (qkv + o + ug + d entries of the quantizer that run used)
+so that the solver's formula reproduces the measured step for that (merged) model: rotations, norms, attention, lm_head.
 
     python perf/latency_finish.py --parts gpurun_out/lat_part*.jsonl --decode gpurun_out/decode_tcomb67.json
       -> perf/latency/3_8b_latency_coeffs_mi355x.json  and  perf/latency/3_8b_latency_coeffs_mi355x.pt
@@ -45,13 +44,20 @@ def main():
         with open(args.decode) as f:
             dec = json.loads([l for l in f if l.startswith("{")][-1])
         q = dec["quantizer"]
-        linears = dec["layers"] * sum(table[f"{lk}_{q}_False"] for lk in UNFUSED)
-        const = max(0.0, dec["ms_whole_step"] * 1e-3 - linears)
+        # The fused-glue step (perf/decode_llama.py: RMSNorm / rotation inside the GEMV launches, one attention launch) is what a
+        # MI355X decode runs; it launches q|k|v and up|gate as ONE launch each, so the matching table entries are the merged ones.
+        if dec.get("ms_fused_glue"):
+            linears = dec["layers"] * sum(table[f"{lk}_{q}_False"] for lk in ["qkv", "o", "ug", "d"])
+            step, what = dec["ms_fused_glue"], "fused-glue step"
+        else:
+            linears = dec["layers"] * sum(table[f"{lk}_{q}_False"] for lk in UNFUSED)
+            step, what = dec["ms_whole_step"], "modular step (torch glue)"
+        const = max(0.0, step * 1e-3 - linears)
         table["constant"] = const
-        table["_constant_doc"] = (f"seconds; measured: perf/decode_llama.py whole step {dec['ms_whole_step']:.3f} ms (model {dec['model']}, "
-                                  f"{dec['layers']} layers, {q}, context {dec['context']}) minus {dec['layers']} x the table's unfused "
-                                  f"q,k,v,o,g,u,d entries ({linears * 1e3:.3f} ms); projections-only graph of the same run: "
-                                  f"{dec['ms_projections_only']:.3f} ms")
+        table["_constant_doc"] = (f"seconds; measured: perf/decode_llama.py {what} {step:.3f} ms (model {dec['model']}, "
+                                  f"{dec['layers']} layers, {q}, context {dec['context']}) minus {dec['layers']} x the table's "
+                                  f"{'qkv,o,ug,d' if dec.get('ms_fused_glue') else 'q,k,v,o,g,u,d'} entries ({linears * 1e3:.3f} ms); the same "
+                                  f"run's modular step (Incoherent* modules + ~1700 torch glue launches): {dec['ms_whole_step']:.3f} ms")
     table["_n"] = sum(1 for k in table if not k.startswith("_"))
     with open(args.table, "w") as f:
         json.dump(table, f, indent=0, sort_keys=True)

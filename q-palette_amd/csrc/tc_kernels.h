@@ -256,7 +256,7 @@ struct StreamView {
 };
 
 #ifdef QPAL_STAMPS
-#define QPAL_STAMP(i) do { if (p.dbg && lane == 0 && gitem == (int)blockIdx.x) p.dbg[((long)blockIdx.x * 16 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define QPAL_STAMP(i) do { if (p.dbg && lane == 0 && gitem == (int)blockIdx.x) p.dbg[((long)blockIdx.x * 16 + wave) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define QPAL_STAMP(i) do { } while (0)
 #endif

@@ -31,22 +31,28 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
         hipDeviceSynchronize();
         unsigned long long *h = (unsigned long long *)malloc(nb);
         hipMemcpy(h, d, nb, hipMemcpyDeviceToHost);
+        // s_memrealtime: 100 MHz, one clock for the whole device (10 ns steps) — spans across workgroups are meaningful
         unsigned long long t0 = ~0ull, t7 = 0;
-        double ph[8] = {0};
+        double ph[8] = {0}, phmax[8] = {0};
+        int nw = 0;
         for (int w = 0; w < grid * 16; w++) {
+            if (!h[w * 8] || !h[w * 8 + 7]) continue;  // wave of a narrower workgroup
+            nw++;
             if (h[w * 8] < t0) t0 = h[w * 8];
             if (h[w * 8 + 7] > t7) t7 = h[w * 8 + 7];
             unsigned long long prev = h[w * 8];
             for (int i = 1; i < 8; i++) {  // a stamp the path did not pass (early staging skips 2 and 3) reads 0: zero-length phase
                 const unsigned long long cur = h[w * 8 + i] ? h[w * 8 + i] : prev;
-                ph[i] += (double)(cur - prev);
+                const double d = (double)(cur - prev);
+                ph[i] += d;
+                if (d > phmax[i]) phmax[i] = d;
                 prev = cur;
             }
         }
-        printf("[stamps] grid %d m %d k %d wpr %d sk %d: span %.2f (units of 100 shader cycles, s_memtime); mean per-wave phase:", grid, p.nrows * 32, p.k, 1 << p.log2_wpr, p.sk,
-               (t7 - t0) / 100.0);
+        printf("[stamps] %s grid %d m %d k %d wpr %d sk %d: first stamp -> last stamp %.2f us; mean / max per-wave phase (us):", ROT ? "ROT" : "plain", grid,
+               p.nrows * 32, p.k, 1 << p.log2_wpr, p.sk, (t7 - t0) / 100.0);
         const char *nm[8] = {"", "issue-w", "x+lut", "barrier", "steps", "xor-red", "barrier2", "final"};
-        for (int i = 1; i < 8; i++) printf(" %s %.2f", nm[i], ph[i] / (grid * 16) / 100.0);
+        for (int i = 1; i < 8; i++) printf(" %s %.2f/%.2f", nm[i], ph[i] / (nw ? nw : 1) / 100.0, phmax[i] / 100.0);
         printf("\n");
         free(h);
         hipFree(d);
