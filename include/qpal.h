@@ -241,11 +241,16 @@ int qpal_attn_decode(const void *q_f16, const void *kcache_f16, const void *vcac
 
 /* The two launches above as one (what a decode step runs): rotary embedding of the new token's q / k, k and v appended to the
  * cache at *pos, attention over positions 0 .. *pos, fp16 out [nq][hd].  q / k / v fp32 as for qpal_rope_kv.  hd in {64, 128,
- * 256}; max_len % 4 == 0, up to ~38 k positions.  The new row is read from on-chip memory by every head of its group: nothing
- * this launch reads was written by it.                                                                                    */
+ * 256}; max_len % 4 == 0.  The new row is read from on-chip memory by every head of its group: nothing this launch reads was
+ * written by it.  ws == NULL: one workgroup per query head (scores of the whole context in LDS: max_len up to ~38 k).
+ * ws != NULL (qpal_attn_ws_bytes(...) > 0 bytes of device memory, 4-byte aligned, zero-filled ONCE, kept across launches):
+ * split-context form for long caches — workgroup (kv head, chunk of the context) serves all nq / nkv query heads of its group,
+ * the last workgroup of a kv head to arrive merges the partial softmaxes.  qpal_attn_ws_bytes returns 0 where the split form
+ * does not apply (max_len < 2048, nq / nkv not in {1, 2, 4, 8}, (nq / nkv) * hd > 1024): pass ws = NULL then.               */
+long qpal_attn_ws_bytes(int nq, int nkv, int hd, long max_len);
 int qpal_attn_rope_decode(const float *q, const float *k, const float *v, void *kcache_f16, void *vcache_f16, void *out_f16,
                           const long *pos, const float *inv_freq, int nq, int nkv, int hd, long max_len, float scale,
-                          void *stream);
+                          void *ws, long ws_bytes, void *stream);
 
 /* 1 if the GEMV entry points can apply the rotation themselves (x_had): k in {2048, 4096} at batch 1 (the
  * decode case); 0 otherwise (then call qpal_hadamard first). */

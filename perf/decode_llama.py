@@ -106,6 +106,7 @@ def main(argv=None):
     ap.add_argument("--start-pos", type=int, default=8, help="position of the first timed token (the cache below it is attended over)")
     ap.add_argument("--vocab", type=int, default=128256)
     ap.add_argument("--no-fused", action="store_true", help="skip the fused-glue step (third figure)")
+    ap.add_argument("--no-split-attention", action="store_true", help="one workgroup per query head at every context length")
     ap.add_argument("--no-modular", action="store_true", help="time the fused-glue step only (profiling)")
     args = ap.parse_args(argv)
     if not torch.cuda.is_available():
@@ -191,6 +192,9 @@ def main(argv=None):
     qkv32 = torch.zeros(1, H + 2 * kv_out, dtype=torch.float32, device=dev)
     ug32 = torch.zeros(1, 2 * I, dtype=torch.float32, device=dev)
     eps = layers[0].input_layernorm.eps
+    # long caches: split-context attention (one workspace serves every layer: launches are stream-ordered)
+    attn_ws_bytes = 0 if args.no_split_attention else nat.lib().qpal_attn_ws_bytes(nq, nkv, head_dim, args.context)
+    attn_ws = torch.zeros(max(attn_ws_bytes, 4) // 4, dtype=torch.float32, device=dev)
 
     def fused_layer(idx, layer, mask):
         att, mlp = layer.self_attn, layer.mlp
@@ -203,6 +207,7 @@ def main(argv=None):
             rc = nat.lib().qpal_attn_rope_decode(parts["q"].data_ptr(), parts["k"].data_ptr(), parts["v"].data_ptr(),
                                                  cache.k[idx].data_ptr(), cache.v[idx].data_ptr(), a16.data_ptr(), pos.data_ptr(),
                                                  inv_freq.data_ptr(), nq, nkv, head_dim, args.context, 1.0 / math.sqrt(head_dim),
+                                                 attn_ws.data_ptr() if attn_ws_bytes else None, attn_ws_bytes,
                                                  torch.cuda.current_stream(dev).cuda_stream)
         nat.check(rc, "qpal_attn_rope_decode")
         qp.multi_gemv([att.o_proj], a16, outs=[h32], outs_zeroed=True, wscales=[att.Wscale_o], oscale=att.scale,

@@ -134,47 +134,45 @@ struct AttnRopeParams {
     float scale;
 };
 
-template <int HD>
-__global__ __launch_bounds__(1024) void attn_rope_decode_kernel(const AttnRopeParams p) {
-    constexpr int NT = 1024, NW = 16, HALF = HD / 2;
+// body: one workgroup of NW waves = one query head; `cap` = positions the score buffer holds (pos < cap)
+template <int HD, int NW>
+__device__ __forceinline__ void attn_rope_head(const AttnRopeParams &p, float *sh, const int head, const long pos, const long cap) {
+    constexpr int NT = 64 * NW, HALF = HD / 2;
     constexpr int LPR = HD / 8;        // lanes per cache row in the score loop
     constexpr int RPW = 64 / LPR;      // rows per wave instruction
     constexpr int DPL = HD / 64;       // dims per lane in the value loop
     static_assert(HD == 64 || HD == 128 || HD == 256, "head dims of the Llama family");
-    extern __shared__ float sh[];  // scores [max_len] | q, new k (fp16 bits) [HD/2 dwords each] | new v [HD] | partial out [NW][HD] | reduce [2 NW]
-    float *sc = sh, *vn = sh + p.max_len + 2 * HALF, *po = vn + HD, *red = po + NW * HD;
-    uint32_t *qh = reinterpret_cast<uint32_t *>(sh + p.max_len), *knh = qh + HALF;
-    const int head = blockIdx.x, rep = p.nq / p.nkv, kh = head / rep;
+    // sh: scores [cap] | q, new k (fp16 bits) [HD/2 dwords each] | new v [HD] | partial out [NW][HD] | reduce [2 NW]
+    float *sc = sh, *vn = sh + cap + 2 * HALF, *po = vn + HD, *red = po + NW * HD;
+    uint32_t *qh = reinterpret_cast<uint32_t *>(sh + cap), *knh = qh + HALF;
+    const int rep = p.nq / p.nkv, kh = head / rep;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long pos = *p.pos;
     const gptr<const uint16_t> K = as_global(p.kcache) + (long)kh * p.max_len * HD, V = as_global(p.vcache) + (long)kh * p.max_len * HD;
 
     // ---- new token: rope(q) -> LDS as fp16 pairs, rope(k), v -> LDS (+ cache, first head of the group)
-    if (tid < 2 * HALF) {
-        const bool is_k = tid >= HALF;
-        const int i = is_k ? tid - HALF : tid;
-        const float *src = is_k ? p.k + (long)kh * HD : p.q + (long)head * HD;
-        const float ang = (float)pos * p.inv_freq[i];
-        const _Float16 c = (_Float16)cosf(ang), s = (_Float16)sinf(ang);
-        const _Float16 x1 = (_Float16)src[i], x2 = (_Float16)src[i + HALF];
-        const _Float16 o1 = x1 * c + (-x2) * s, o2 = x2 * c + x1 * s;
-        if (is_k) {
-            reinterpret_cast<uint16_t *>(knh)[i] = __builtin_bit_cast(uint16_t, o1);
-            reinterpret_cast<uint16_t *>(knh)[i + HALF] = __builtin_bit_cast(uint16_t, o2);
-            if (head % rep == 0) {
+    for (int idx = tid; idx < 2 * HALF + HD; idx += NT) {
+        if (idx < 2 * HALF) {
+            const bool is_k = idx >= HALF;
+            const int i = is_k ? idx - HALF : idx;
+            const float *src = is_k ? p.k + (long)kh * HD : p.q + (long)head * HD;
+            const float ang = (float)pos * p.inv_freq[i];
+            const _Float16 c = (_Float16)cosf(ang), s = (_Float16)sinf(ang);
+            const _Float16 x1 = (_Float16)src[i], x2 = (_Float16)src[i + HALF];
+            const _Float16 o1 = x1 * c + (-x2) * s, o2 = x2 * c + x1 * s;
+            uint16_t *dst16 = reinterpret_cast<uint16_t *>(is_k ? knh : qh);
+            dst16[i] = __builtin_bit_cast(uint16_t, o1);
+            dst16[i + HALF] = __builtin_bit_cast(uint16_t, o2);
+            if (is_k && head % rep == 0) {
                 uint16_t *dst = p.kcache + ((long)kh * p.max_len + pos) * HD;
                 dst[i] = __builtin_bit_cast(uint16_t, o1);
                 dst[i + HALF] = __builtin_bit_cast(uint16_t, o2);
             }
         } else {
-            reinterpret_cast<uint16_t *>(qh)[i] = __builtin_bit_cast(uint16_t, o1);
-            reinterpret_cast<uint16_t *>(qh)[i + HALF] = __builtin_bit_cast(uint16_t, o2);
+            const int d = idx - 2 * HALF;
+            const _Float16 hv = (_Float16)p.v[(long)kh * HD + d];
+            vn[d] = (float)hv;
+            if (head % rep == 0) p.vcache[((long)kh * p.max_len + pos) * HD + d] = __builtin_bit_cast(uint16_t, hv);
         }
-    } else if (tid < 2 * HALF + HD) {
-        const int d = tid - 2 * HALF;
-        const _Float16 hv = (_Float16)p.v[(long)kh * HD + d];
-        vn[d] = (float)hv;
-        if (head % rep == 0) p.vcache[((long)kh * p.max_len + pos) * HD + d] = __builtin_bit_cast(uint16_t, hv);
     }
     __syncthreads();
 
@@ -245,7 +243,6 @@ __global__ __launch_bounds__(1024) void attn_rope_decode_kernel(const AttnRopePa
     float acc[DPL];
 #pragma unroll
     for (int e = 0; e < DPL; e++) acc[e] = 0.f;
-    typedef uint16_t dims_t __attribute__((ext_vector_type(DPL)));
     for (long t0 = wave; t0 < pos; t0 += NW * 4) {
         uint16_t raw[4][DPL];
         float w4[4];
@@ -271,12 +268,334 @@ __global__ __launch_bounds__(1024) void attn_rope_decode_kernel(const AttnRopePa
 #pragma unroll
     for (int e = 0; e < DPL; e++) po[wave * HD + DPL * lane + e] = acc[e];
     __syncthreads();
-    if (tid < HD) {
+    for (int d = tid; d < HD; d += NT) {
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; w++) v += po[w * HD + tid];
-        p.out[(long)head * HD + tid] = __builtin_bit_cast(uint16_t, (_Float16)(v / sum));
+        for (int w = 0; w < NW; w++) v += po[w * HD + d];
+        p.out[(long)head * HD + d] = __builtin_bit_cast(uint16_t, (_Float16)(v / sum));
     }
+}
+
+template <int HD>
+__global__ __launch_bounds__(1024) void attn_rope_decode_kernel(const AttnRopeParams p) {
+    extern __shared__ float sh[];
+    attn_rope_head<HD, 16>(p, sh, blockIdx.x, *p.pos, p.max_len);
+}
+
+// Split-context form of the above for long caches (flash-decoding shape).  One workgroup per query head streams the whole
+// K and V of its kv head through ONE compute unit: 2 MiB at 4 k positions = 56 us per layer (measured), 14x the HBM time.
+// Here workgroup (kv head, split) takes one chunk of the context for ALL `REP` query heads of the group (K and V are read once
+// per group instead of once per head), leaves a partial (max, sum, unnormalised out) per head in a workspace and takes a
+// ticket; the last workgroup of a kv head to arrive merges the partials (agent-scope stores and loads: the L2s of the 8 XCDs
+// are not coherent with each other) and resets the ticket for the next launch.
+constexpr long kAttnPlainBelow = 768;  // positions below which the split-context launch runs the one-workgroup-per-head body
+
+struct AttnSplitParams {
+    AttnRopeParams a;
+    float *ws;          // [nkv][nsplit][REP][HD + 2] partials, then nkv tickets (zero-filled once by the caller)
+    int nsplit, chunk;  // chunk: positions per split (multiple of 64)
+};
+
+__device__ __forceinline__ void st_agent_f(float *p, float v) {
+    __hip_atomic_store(as_global(reinterpret_cast<unsigned *>(p)), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent_f(const float *p) {
+    return __builtin_bit_cast(float, __hip_atomic_load(as_global(reinterpret_cast<const unsigned *>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <int HD, int REP, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSplitParams sp) {
+    constexpr int NT = 64 * NW, HALF = HD / 2;
+    constexpr int LPR = HD / 8, DPL = HD / 64;
+    static_assert(REP * HD <= 1024, "partial-out buffer: NW x REP x HD floats of LDS");
+    const AttnRopeParams &p = sp.a;
+    extern __shared__ float sh[];  // scores [REP][chunk] | q [REP][HD/2 dwords] | new k [HD/2 dwords] | new v [HD] | partial out [NW][REP][HD] | reduce [2 NW REP] | new-position scores [REP] | flag
+    const int CL = sp.chunk;
+    float *sc = sh;
+    uint32_t *qh = reinterpret_cast<uint32_t *>(sh + REP * CL), *knh = qh + REP * HALF;
+    float *vn = reinterpret_cast<float *>(knh + HALF), *po = vn + HD, *red = po + NW * REP * HD;
+    float *park = red + 2 * NW * REP;
+    unsigned *flag = reinterpret_cast<unsigned *>(park + REP);
+    const int kh = blockIdx.x / sp.nsplit, split = blockIdx.x - kh * sp.nsplit;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long pos = *p.pos;
+    // A short context in a long cache: the first nq workgroups run the one-head body, the others leave.  Measured per launch
+    // (32 heads, 8 kv heads, hd 128): one-head body 4.9 us at 40 positions, 9.8 at 500, 28.5 at 2000, 62 at 4000, 457 at 32 k;
+    // this kernel's group form 12.6 at 500, 16.5 at 2000, 18.4 at 4000, 38 at 32 k (134 MB: 3.5 TB/s) — its floor is the
+    // partial / ticket / merge round trips at agent scope.
+    if (pos < kAttnPlainBelow) {
+        if ((int)blockIdx.x < p.nq) attn_rope_head<HD, NW>(p, sh, blockIdx.x, pos, kAttnPlainBelow);
+        return;
+    }
+    // The context that EXISTS is cut evenly over the splits (chunks of a multiple of 64 positions, at most the static `chunk`
+    // the LDS score buffer was sized for): a 500-position context in a 32 k cache still spreads over 8 chunks per kv head
+    // instead of sitting in one.  Chunks 0 .. neff-1 hold positions <= pos (the last of them the new one); the workgroups of
+    // the others leave at once and take no ticket.
+    long cld = ((pos + sp.nsplit) / sp.nsplit + 63) / 64 * 64;
+    if (cld > CL) cld = CL;
+    const long c0 = (long)split * cld;
+    const int neff = (int)(pos / cld) + 1;
+    if (split >= neff) return;
+    const bool owner = split == neff - 1;                    // this chunk holds the new position
+    const long cend = pos < c0 + cld ? pos : c0 + cld;       // cached positions of the chunk: [c0, cend)
+    const int nc = cend > c0 ? (int)(cend - c0) : 0;         // their number
+    const gptr<const uint16_t> K = as_global(p.kcache) + (long)kh * p.max_len * HD, V = as_global(p.vcache) + (long)kh * p.max_len * HD;
+    float *wsp = sp.ws + ((long)(kh * sp.nsplit + split) * REP) * (HD + 2);
+    unsigned *ticket = reinterpret_cast<unsigned *>(sp.ws + (long)p.nkv * sp.nsplit * REP * (HD + 2)) + kh;
+
+    {  // every participating chunk holds at least one position (the earlier ones are full, the last one has the new position)
+        // ---- new token: rope of the group's REP query heads (+ k, v in the chunk that owns the new position)
+        for (int idx = tid; idx < (REP + 1) * HALF; idx += NT) {
+            const int hh = idx / HALF, i = idx - hh * HALF;
+            const bool is_k = hh == REP;
+            if (is_k && !owner) continue;
+            const float *src = is_k ? p.k + (long)kh * HD : p.q + (long)(kh * REP + hh) * HD;
+            const float ang = (float)pos * p.inv_freq[i];
+            const _Float16 c = (_Float16)cosf(ang), s = (_Float16)sinf(ang);
+            const _Float16 x1 = (_Float16)src[i], x2 = (_Float16)src[i + HALF];
+            const _Float16 o1 = x1 * c + (-x2) * s, o2 = x2 * c + x1 * s;
+            uint16_t *dst16 = reinterpret_cast<uint16_t *>(is_k ? knh : qh + hh * HALF);
+            dst16[i] = __builtin_bit_cast(uint16_t, o1);
+            dst16[i + HALF] = __builtin_bit_cast(uint16_t, o2);
+            if (is_k) {
+                uint16_t *dst = p.kcache + ((long)kh * p.max_len + pos) * HD;
+                dst[i] = __builtin_bit_cast(uint16_t, o1);
+                dst[i + HALF] = __builtin_bit_cast(uint16_t, o2);
+            }
+        }
+        if (owner) {
+            for (int d = tid; d < HD; d += NT) {
+                const _Float16 hv = (_Float16)p.v[(long)kh * HD + d];
+                vn[d] = (float)hv;
+                p.vcache[((long)kh * p.max_len + pos) * HD + d] = __builtin_bit_cast(uint16_t, hv);
+            }
+        }
+        __syncthreads();
+
+        // ---- scores
+        const int grp = lane / LPR, sl = lane % LPR;
+        u32x4 qv[REP];
+#pragma unroll
+        for (int h = 0; h < REP; h++) qv[h] = *reinterpret_cast<const u32x4 *>(qh + h * HALF + 4 * sl);
+        float mx[REP];
+#pragma unroll
+        for (int h = 0; h < REP; h++) mx[h] = -3.0e38f;
+        // Scores on the matrix pipe: D[head][position] = Q[head][:] . K[position][:], v_mfma_f32_16x16x32_f16 with the group's
+        // query heads as the (zero-padded) 16 rows of A and 16 cache rows as B.  A B fragment is lane (column j = position,
+        // q = lane >> 4): 8 consecutive dims 32 kc + 8 q .. of row j = one 16-byte load; the wave's HD/32 loads cover 16 whole
+        // rows.  No cross-lane reduction, no VALU beside the scale: the dot-product form (v_dot2 + a 4-step xor reduction per
+        // head and row group) made a chunk VALU-bound — 500 positions for 4 heads: 19.7 us on one CU.
+        constexpr int U = 2;    // 16-row tiles in flight per wave
+        constexpr int KC = HD / 32;
+        typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+        typedef float float4_t __attribute__((ext_vector_type(4)));
+        const int mi = lane & 15, mq = lane >> 4;
+        half8_t afr[KC];
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+            u32x4 a{0u, 0u, 0u, 0u};
+            if (mi < REP) a = *reinterpret_cast<const u32x4 *>(qh + mi * HALF + 16 * kc + 4 * mq);
+            afr[kc] = __builtin_bit_cast(half8_t, a);
+        }
+        for (int t0 = wave * 16; t0 < nc; t0 += NW * 16 * U) {
+            u32x4 kb[U][KC];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int t = t0 + u * NW * 16 + mi;
+                const gptr<const uint16_t> row = K + (c0 + (t < nc ? t : 0)) * HD + 8 * mq;
+#pragma unroll
+                for (int kc = 0; kc < KC; kc++) kb[u][kc] = *(gptr<const u32x4>)(row + 32 * kc);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int t = t0 + u * NW * 16 + mi;
+                float4_t d{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kc = 0; kc < KC; kc++)
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[kc], __builtin_bit_cast(half8_t, kb[u][kc]), d, 0, 0, 0);
+                // lane (mq, mi): rows 4 mq + r (heads), column mi (position t)
+#pragma unroll
+                for (int h = 0; h < REP; h++) {
+                    if ((h >> 2) == mq && t < nc) {
+                        const float a = d[h & 3] * p.scale;
+                        sc[h * CL + t] = a;
+                        mx[h] = a > mx[h] ? a : mx[h];
+                    }
+                }
+            }
+        }
+        if (owner && wave == NW - 1) {  // the new position, from LDS (its score is parked apart: the chunk's nc may equal CL)
+            u32x4 kn = u32x4{0u, 0u, 0u, 0u};
+            if (grp == 0) kn = *reinterpret_cast<const u32x4 *>(knh + 4 * sl);
+#pragma unroll
+            for (int h = 0; h < REP; h++) {
+                float a = fdot2(kn.x, qv[h].x, 0.f);
+                a = fdot2(kn.y, qv[h].y, a);
+                a = fdot2(kn.z, qv[h].z, a);
+                a = fdot2(kn.w, qv[h].w, a);
+#pragma unroll
+                for (int sft = 1; sft < LPR; sft <<= 1) a += __shfl_xor(a, sft, 64);
+                a *= p.scale;
+                if (lane == 0) park[h] = a;
+                if (grp == 0) mx[h] = a > mx[h] ? a : mx[h];
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < REP; h++) {
+            float m = mx[h];
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) { const float o = __shfl_xor(m, sft, 64); m = o > m ? o : m; }
+            if (lane == 0) red[h * NW + wave] = m;
+        }
+        __syncthreads();
+        float snew[REP];
+#pragma unroll
+        for (int h = 0; h < REP; h++) {
+            float m = red[h * NW];
+#pragma unroll
+            for (int w = 1; w < NW; w++) m = red[h * NW + w] > m ? red[h * NW + w] : m;
+            mx[h] = m;
+            snew[h] = owner ? park[h] : 0.f;
+        }
+        float sum[REP];
+#pragma unroll
+        for (int h = 0; h < REP; h++) {
+            float s = 0.f;
+            for (int t = tid; t < nc; t += NT) {
+                const float e = __expf(sc[h * CL + t] - mx[h]);
+                sc[h * CL + t] = e;
+                s += e;
+            }
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) s += __shfl_xor(s, sft, 64);
+            if (lane == 0) red[NW * REP + h * NW + wave] = s;
+            snew[h] = owner ? __expf(snew[h] - mx[h]) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < REP; h++) {
+            float s = snew[h];
+#pragma unroll
+            for (int w = 0; w < NW; w++) s += red[NW * REP + h * NW + w];
+            sum[h] = s;
+        }
+
+        // ---- values
+        float acc[REP][DPL];
+#pragma unroll
+        for (int h = 0; h < REP; h++)
+#pragma unroll
+            for (int e = 0; e < DPL; e++) acc[h][e] = 0.f;
+        constexpr int UV = 4;   // rows in flight per wave in the value loop (latency-bound: one wave = a serial chain of loads)
+        for (int t0 = wave; t0 < nc; t0 += NW * UV) {
+            uint16_t raw[UV][DPL];
+#pragma unroll
+            for (int u = 0; u < UV; u++) {
+                const int t = t0 + u * NW;
+                const gptr<const uint16_t> row = V + (c0 + (t < nc ? t : 0)) * HD + DPL * lane;
+                if constexpr (DPL == 1) raw[u][0] = row[0];
+                else if constexpr (DPL == 2) { const uint32_t r = *(gptr<const uint32_t>)row; raw[u][0] = (uint16_t)r; raw[u][1] = (uint16_t)(r >> 16); }
+                else { const u32x2 r = *(gptr<const u32x2>)row; raw[u][0] = (uint16_t)r.x; raw[u][1] = (uint16_t)(r.x >> 16); raw[u][2] = (uint16_t)r.y; raw[u][3] = (uint16_t)(r.y >> 16); }
+            }
+#pragma unroll
+            for (int u = 0; u < UV; u++) {
+                const int t = t0 + u * NW;
+#pragma unroll
+                for (int h = 0; h < REP; h++) {
+                    const float w = t < nc ? sc[h * CL + t] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < DPL; e++) acc[h][e] += w * (float)__builtin_bit_cast(_Float16, raw[u][e]);
+                }
+            }
+        }
+        if (owner && wave == 0) {
+#pragma unroll
+            for (int h = 0; h < REP; h++)
+#pragma unroll
+                for (int e = 0; e < DPL; e++) acc[h][e] += snew[h] * vn[DPL * lane + e];
+        }
+#pragma unroll
+        for (int h = 0; h < REP; h++)
+#pragma unroll
+            for (int e = 0; e < DPL; e++) po[(wave * REP + h) * HD + DPL * lane + e] = acc[h][e];
+        __syncthreads();
+        if (neff == 1) {  // the only chunk: no partials, no ticket
+#pragma unroll
+            for (int h = 0; h < REP; h++)
+                if (tid == h) park[h] = sum[h];
+            __syncthreads();
+            for (int idx = tid; idx < REP * HD; idx += NT) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; w++) v += po[w * REP * HD + idx];
+                const int h = idx / HD;
+                p.out[(long)(kh * REP) * HD + idx] = __builtin_bit_cast(uint16_t, (_Float16)(v / park[h]));
+            }
+            return;
+        }
+        for (int idx = tid; idx < REP * HD; idx += NT) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; w++) v += po[w * REP * HD + idx];
+            const int h = idx / HD, d = idx - h * HD;
+            st_agent_f(wsp + h * (HD + 2) + 2 + d, v);
+        }
+#pragma unroll
+        for (int h = 0; h < REP; h++) {
+            if (tid == h) {
+                st_agent_f(wsp + h * (HD + 2), mx[h]);
+                st_agent_f(wsp + h * (HD + 2) + 1, sum[h]);
+            }
+        }
+    }
+    // ---- ticket: the stores above are write-through; wait for them, then arrive
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(as_global(ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = t == (unsigned)neff - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*flag == 0u) return;
+    // ---- last arriver of this kv head: merge.  Agent-scope loads are ~1 us each: all of a stage's loads are issued
+    // together (max / sum of every partial through LDS first, then the out partials eight at a time), never one per iteration.
+    const float *base = sp.ws + (long)kh * sp.nsplit * REP * (HD + 2);
+    float *ml = sh;  // [nsplit * REP][2]: the score buffer is free now
+    for (int i = tid; i < neff * REP; i += NT) {
+        const float *pp = base + (long)i * (HD + 2);
+        const float m = ld_agent_f(pp), l = ld_agent_f(pp + 1);
+        ml[2 * i] = m;
+        ml[2 * i + 1] = l;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < REP * HD; idx += NT) {
+        const int h = idx / HD, d = idx - h * HD;
+        float M = -3.0e38f;
+        for (int s = 0; s < neff; s++) {
+            const float m = ml[2 * (s * REP + h)];
+            M = m > M ? m : M;
+        }
+        float L = 0.f, o = 0.f;
+        for (int s0 = 0; s0 < neff; s0 += 32) {
+            float v[32];
+#pragma unroll
+            for (int u = 0; u < 32; u++) {
+                const int sx = s0 + u < neff ? s0 + u : neff - 1;
+                v[u] = ld_agent_f(base + ((long)sx * REP + h) * (HD + 2) + 2 + d);
+            }
+#pragma unroll
+            for (int u = 0; u < 32; u++) {
+                const int sx = s0 + u;
+                if (sx < neff) {
+                    const float f = __expf(ml[2 * (sx * REP + h)] - M);
+                    L += ml[2 * (sx * REP + h) + 1] * f;
+                    o += v[u] * f;
+                }
+            }
+        }
+        p.out[(long)(kh * REP + h) * HD + d] = __builtin_bit_cast(uint16_t, (_Float16)(o / L));
+    }
+    if (tid == 0) __hip_atomic_store(as_global(ticket), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace qpal
@@ -315,30 +634,80 @@ extern "C" int qpal_rope_kv(const float *q, const float *k, const float *v, void
     return (int)hipGetLastError();
 }
 
+// split geometry for a cache of max_len positions (0 splits: use the one-workgroup-per-head kernel)
+static void attn_split_geometry(int nq, int nkv, int hd, long max_len, int &nsplit, int &chunk, int &waves, size_t &lds, size_t &ws_bytes) {
+    nsplit = 0, chunk = 0, waves = 0, lds = 0, ws_bytes = 0;
+    const int rep = nq / nkv;
+    if (max_len < 2048 || (rep != 1 && rep != 2 && rep != 4 && rep != 8) || rep * hd > 1024) return;
+    int want = 256 / nkv;
+    if (want < 2) want = 2;
+    if (want > 64) want = 64;
+    long c = (max_len + want - 1) / want;
+    c = (c + 63) / 64 * 64;
+    const int ns = (int)((max_len + c - 1) / c);
+    // 16 waves whatever the chunk: with 4 (tried for short chunks) every wave walks 4x the rows, one load latency at a time
+    // (8192-position cache at 500 positions: 30 us against 10)
+    const int nw = 16;
+    const size_t floats = (size_t)rep * c + (size_t)rep * hd / 2 + hd / 2 + hd + nw * (size_t)rep * hd + 2 * nw * (size_t)rep + rep + 4;
+    const size_t plain = (size_t)kAttnPlainBelow + 2 * hd + nw * (size_t)hd + 2 * nw;  // attn_rope_head's layout at cap = kAttnPlainBelow
+    const size_t need = floats > plain ? floats : plain;
+    if (ns < 2 || nkv * ns < nq || need * sizeof(float) > 160 * 1024) return;
+    nsplit = ns, chunk = (int)c, waves = nw, lds = need * sizeof(float);
+    ws_bytes = ((size_t)nkv * ns * rep * (hd + 2) + nkv) * sizeof(float);
+}
+
+extern "C" long qpal_attn_ws_bytes(int nq, int nkv, int hd, long max_len) {
+    if (nq < 1 || nkv < 1 || nq % nkv || max_len < 1) return 0;
+    int ns, ch, nw;
+    size_t lds, wsb;
+    attn_split_geometry(nq, nkv, hd, max_len, ns, ch, nw, lds, wsb);
+    return (long)wsb;
+}
+
+template <class Kern, class Params>
+static int launch_attn(Kern kern, const Params &p, int grid, int threads, size_t lds, void *stream) {
+    static bool attr_set[64] = {};  // one latch per instantiation
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (lds > 64 * 1024 && (dev < 0 || !attr_set[dev])) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, static_cast<hipStream_t>(stream), p);
+    return (int)hipGetLastError();
+}
+
 extern "C" int qpal_attn_rope_decode(const float *q, const float *k, const float *v, void *kcache_f16, void *vcache_f16, void *out_f16,
                                      const long *pos, const float *inv_freq, int nq, int nkv, int hd, long max_len, float scale,
-                                     void *stream) {
+                                     void *ws, long ws_bytes, void *stream) {
     if (!q || !k || !v || !kcache_f16 || !vcache_f16 || !out_f16 || !pos || !inv_freq) return QPAL_E_NULL;
     if (nq < 1 || nkv < 1 || nq % nkv || max_len < 1 || (hd != 64 && hd != 128 && hd != 256)) return QPAL_E_SHAPE;
-    const size_t lds = sizeof(float) * ((size_t)max_len + 2 * hd + 16 * (size_t)hd + 32);
-    if (lds > 160 * 1024) return QPAL_E_SHAPE;  // ~38 k positions: longer contexts need a split-context form
     if ((reinterpret_cast<uintptr_t>(kcache_f16) | reinterpret_cast<uintptr_t>(vcache_f16)) & 15) return QPAL_E_ALIGN;
     if (max_len % 4) return QPAL_E_ALIGN;  // the fp16 q block behind the scores is read with 16-byte LDS loads
     AttnRopeParams p{q, k, v, static_cast<uint16_t *>(kcache_f16), static_cast<uint16_t *>(vcache_f16),
                      static_cast<uint16_t *>(out_f16), pos, inv_freq, nq, nkv, max_len, scale};
-    auto launch = [&](auto kern) -> int {
-        static bool attr_set[64] = {};  // one latch per instantiation (the lambda is instantiated per kernel type)
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
-        if (lds > 64 * 1024 && (dev < 0 || !attr_set[dev])) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return (int)e;
-            if (dev >= 0) attr_set[dev] = true;
-        }
-        hipLaunchKernelGGL(kern, dim3(nq), dim3(1024), lds, static_cast<hipStream_t>(stream), p);
-        return (int)hipGetLastError();
-    };
-    if (hd == 64) return launch(attn_rope_decode_kernel<64>);
-    if (hd == 128) return launch(attn_rope_decode_kernel<128>);
-    return launch(attn_rope_decode_kernel<256>);
+    int ns, ch, nw;
+    size_t slds, wsb;
+    attn_split_geometry(nq, nkv, hd, max_len, ns, ch, nw, slds, wsb);
+    if (ws && ns >= 2) {  // split-context form
+        if ((size_t)ws_bytes < wsb) return QPAL_E_SHAPE;
+        if (reinterpret_cast<uintptr_t>(ws) & 3) return QPAL_E_ALIGN;
+        AttnSplitParams sp{p, static_cast<float *>(ws), ns, ch};
+        const int rep = nq / nkv, grid = nkv * ns;
+#define QPAL_SPLIT(HD_, REP_)                                                                                              \
+    if (hd == HD_ && rep == REP_)                                                                                          \
+        return nw == 4 ? launch_attn(attn_rope_split_kernel<HD_, REP_, 4>, sp, grid, 256, slds, stream)                    \
+                       : launch_attn(attn_rope_split_kernel<HD_, REP_, 16>, sp, grid, 1024, slds, stream);
+        QPAL_SPLIT(64, 1) QPAL_SPLIT(64, 2) QPAL_SPLIT(64, 4) QPAL_SPLIT(64, 8)
+        QPAL_SPLIT(128, 1) QPAL_SPLIT(128, 2) QPAL_SPLIT(128, 4) QPAL_SPLIT(128, 8)
+        QPAL_SPLIT(256, 1) QPAL_SPLIT(256, 2) QPAL_SPLIT(256, 4)
+#undef QPAL_SPLIT
+        return QPAL_E_SHAPE;
+    }
+    const size_t lds = sizeof(float) * ((size_t)max_len + 2 * hd + 16 * (size_t)hd + 32);
+    if (lds > 160 * 1024) return QPAL_E_SHAPE;  // ~38 k positions: give a workspace (qpal_attn_ws_bytes) for the split-context form
+    if (hd == 64) return launch_attn(attn_rope_decode_kernel<64>, p, nq, 1024, lds, stream);
+    if (hd == 128) return launch_attn(attn_rope_decode_kernel<128>, p, nq, 1024, lds, stream);
+    return launch_attn(attn_rope_decode_kernel<256>, p, nq, 1024, lds, stream);
 }

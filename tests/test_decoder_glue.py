@@ -68,9 +68,17 @@ def test_rope_kv_and_attn_decode_match_torch(qp, nq, nkv, hd, ctx, pos):
     assert torch.allclose(out.view(nq, hd).float(), ref.view(nq, hd), atol=2e-3, rtol=2e-3)
 
 
-@pytest.mark.parametrize("nq,nkv,hd,ctx,pos", [(32, 8, 128, 256, 17), (8, 8, 64, 64, 0), (64, 8, 128, 4096, 4095), (16, 4, 256, 512, 100),
-                                                (32, 8, 128, 1024, 1), (32, 8, 128, 2048, 1300)])
-def test_attn_rope_decode_one_launch_matches_torch(qp, nq, nkv, hd, ctx, pos):
+@pytest.mark.parametrize("nq,nkv,hd,ctx,pos,split", [
+    (32, 8, 128, 256, 17, False), (8, 8, 64, 64, 0, False), (64, 8, 128, 4096, 4095, False), (16, 4, 256, 512, 100, False),
+    (32, 8, 128, 1024, 1, False), (32, 8, 128, 2048, 1300, False),
+    # split-context form (workspace given): first / middle / last chunk owning the new position, empty chunks, chunk boundaries
+    (32, 8, 128, 2048, 0, True), (32, 8, 128, 2048, 63, True), (32, 8, 128, 2048, 64, True), (32, 8, 128, 2048, 1300, True),
+    (32, 8, 128, 4096, 4095, True), (64, 8, 128, 8192, 5000, True), (8, 8, 64, 4096, 2049, True), (16, 4, 256, 2048, 2047, True),
+    (32, 8, 128, 32768, 31000, True), (32, 8, 128, 512, 100, True),
+    # below 768 positions the split launch runs the one-head body; above, the existing context is cut evenly over the splits
+    (32, 8, 128, 2048, 767, True), (32, 8, 128, 2048, 768, True), (32, 8, 128, 32768, 800, True), (64, 8, 128, 32768, 1023, True),
+    (32, 8, 128, 32768, 2047, True), (32, 8, 128, 32768, 2048, True)])
+def test_attn_rope_decode_one_launch_matches_torch(qp, nq, nkv, hd, ctx, pos, split):
     """qpal_attn_rope_decode = rope + cache append + attention in one launch: equals the two-launch pair's math (torch
     reference as above), leaves the cache exactly as qpal_rope_kv would, and does not depend on the cache row it writes."""
     dev = torch.device("cuda", 0)
@@ -88,9 +96,18 @@ def test_attn_rope_decode_one_launch_matches_torch(qp, nq, nkv, hd, ctx, pos):
     pos_t = torch.tensor([pos], dtype=torch.long, device=dev)
     out = torch.empty(nq * hd, dtype=torch.float16, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    nat.check(nat.lib().qpal_attn_rope_decode(q32.data_ptr(), k32.data_ptr(), v32.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(),
-                                              pos_t.data_ptr(), inv_freq.data_ptr(), nq, nkv, hd, ctx, 1.0 / math.sqrt(hd), stream),
-              "qpal_attn_rope_decode")
+    ws_bytes = nat.lib().qpal_attn_ws_bytes(nq, nkv, hd, ctx) if split else 0
+    assert (ws_bytes > 0) == (split and ctx >= 2048)
+    ws = torch.zeros(max(ws_bytes, 4) // 4, dtype=torch.float32, device=dev)
+    for rep in range(2):  # twice: the split form's tickets must be back at zero after a launch
+        if rep:
+            kc[:, pos] = float("nan")
+            vc[:, pos] = float("nan")
+            out.fill_(float("nan"))
+        nat.check(nat.lib().qpal_attn_rope_decode(q32.data_ptr(), k32.data_ptr(), v32.data_ptr(), kc.data_ptr(), vc.data_ptr(),
+                                                  out.data_ptr(), pos_t.data_ptr(), inv_freq.data_ptr(), nq, nkv, hd, ctx,
+                                                  1.0 / math.sqrt(hd), ws.data_ptr() if ws_bytes else None, ws_bytes, stream),
+                  "qpal_attn_rope_decode")
     ang = pos_t.float()[:, None] * inv_freq[None, :]
     emb = torch.cat((ang, ang), dim=-1)
     cos, sin = emb.cos().half(), emb.sin().half()
