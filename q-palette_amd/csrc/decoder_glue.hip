@@ -374,9 +374,6 @@ __global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSpli
 
         // ---- scores
         const int grp = lane / LPR, sl = lane % LPR;
-        u32x4 qv[REP];
-#pragma unroll
-        for (int h = 0; h < REP; h++) qv[h] = *reinterpret_cast<const u32x4 *>(qh + h * HALF + 4 * sl);
         float mx[REP];
 #pragma unroll
         for (int h = 0; h < REP; h++) mx[h] = -3.0e38f;
@@ -385,7 +382,7 @@ __global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSpli
         // q = lane >> 4): 8 consecutive dims 32 kc + 8 q .. of row j = one 16-byte load; the wave's HD/32 loads cover 16 whole
         // rows.  No cross-lane reduction, no VALU beside the scale: the dot-product form (v_dot2 + a 4-step xor reduction per
         // head and row group) made a chunk VALU-bound — 500 positions for 4 heads: 19.7 us on one CU.
-        constexpr int U = 2;    // 16-row tiles in flight per wave
+        constexpr int U = REP > 4 ? 1 : 2;  // 16-row tiles in flight per wave (registers: 8 heads keep 8 maxima, sums and accumulators live)
         constexpr int KC = HD / 32;
         typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
         typedef float float4_t __attribute__((ext_vector_type(4)));
@@ -429,10 +426,11 @@ __global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSpli
             if (grp == 0) kn = *reinterpret_cast<const u32x4 *>(knh + 4 * sl);
 #pragma unroll
             for (int h = 0; h < REP; h++) {
-                float a = fdot2(kn.x, qv[h].x, 0.f);
-                a = fdot2(kn.y, qv[h].y, a);
-                a = fdot2(kn.z, qv[h].z, a);
-                a = fdot2(kn.w, qv[h].w, a);
+                const u32x4 qv = *reinterpret_cast<const u32x4 *>(qh + h * HALF + 4 * sl);  // loaded here: not live across the tile loop
+                float a = fdot2(kn.x, qv.x, 0.f);
+                a = fdot2(kn.y, qv.y, a);
+                a = fdot2(kn.z, qv.z, a);
+                a = fdot2(kn.w, qv.w, a);
 #pragma unroll
                 for (int sft = 1; sft < LPR; sft <<= 1) a += __shfl_xor(a, sft, 64);
                 a *= p.scale;
@@ -456,6 +454,7 @@ __global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSpli
             for (int w = 1; w < NW; w++) m = red[h * NW + w] > m ? red[h * NW + w] : m;
             mx[h] = m;
             snew[h] = owner ? park[h] : 0.f;
+            if constexpr (REP > 4) __builtin_amdgcn_sched_barrier(0);  // one head at a time: 8 x 16 hoisted LDS reads spill
         }
         float sum[REP];
 #pragma unroll
@@ -478,6 +477,7 @@ __global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSpli
 #pragma unroll
             for (int w = 0; w < NW; w++) s += red[NW * REP + h * NW + w];
             sum[h] = s;
+            if constexpr (REP > 4) __builtin_amdgcn_sched_barrier(0);
         }
 
         // ---- values
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSpli
         for (int h = 0; h < REP; h++)
 #pragma unroll
             for (int e = 0; e < DPL; e++) acc[h][e] = 0.f;
-        constexpr int UV = 4;   // rows in flight per wave in the value loop (latency-bound: one wave = a serial chain of loads)
+        constexpr int UV = REP * DPL > 8 ? 2 : 4;  // rows in flight per wave in the value loop (latency-bound: one wave = a serial chain of loads)
         for (int t0 = wave; t0 < nc; t0 += NW * UV) {
             uint16_t raw[UV][DPL];
 #pragma unroll
@@ -576,15 +576,15 @@ __global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSpli
             M = m > M ? m : M;
         }
         float L = 0.f, o = 0.f;
-        for (int s0 = 0; s0 < neff; s0 += 32) {
-            float v[32];
+        for (int s0 = 0; s0 < neff; s0 += 16) {
+            float v[16];
 #pragma unroll
-            for (int u = 0; u < 32; u++) {
+            for (int u = 0; u < 16; u++) {
                 const int sx = s0 + u < neff ? s0 + u : neff - 1;
                 v[u] = ld_agent_f(base + ((long)sx * REP + h) * (HD + 2) + 2 + d);
             }
 #pragma unroll
-            for (int u = 0; u < 32; u++) {
+            for (int u = 0; u < 16; u++) {
                 const int sx = s0 + u;
                 if (sx < neff) {
                     const float f = __expf(ml[2 * (sx * REP + h)] - M);
@@ -695,10 +695,8 @@ extern "C" int qpal_attn_rope_decode(const float *q, const float *k, const float
         if (reinterpret_cast<uintptr_t>(ws) & 3) return QPAL_E_ALIGN;
         AttnSplitParams sp{p, static_cast<float *>(ws), ns, ch};
         const int rep = nq / nkv, grid = nkv * ns;
-#define QPAL_SPLIT(HD_, REP_)                                                                                              \
-    if (hd == HD_ && rep == REP_)                                                                                          \
-        return nw == 4 ? launch_attn(attn_rope_split_kernel<HD_, REP_, 4>, sp, grid, 256, slds, stream)                    \
-                       : launch_attn(attn_rope_split_kernel<HD_, REP_, 16>, sp, grid, 1024, slds, stream);
+#define QPAL_SPLIT(HD_, REP_) \
+    if (hd == HD_ && rep == REP_) return launch_attn(attn_rope_split_kernel<HD_, REP_, 16>, sp, grid, 64 * nw, slds, stream);
         QPAL_SPLIT(64, 1) QPAL_SPLIT(64, 2) QPAL_SPLIT(64, 4) QPAL_SPLIT(64, 8)
         QPAL_SPLIT(128, 1) QPAL_SPLIT(128, 2) QPAL_SPLIT(128, 4) QPAL_SPLIT(128, 8)
         QPAL_SPLIT(256, 1) QPAL_SPLIT(256, 2) QPAL_SPLIT(256, 4)
