@@ -89,6 +89,9 @@ typedef struct qpal_tcq_job {
     float x_rms_eps;
     const void *x_rms_w;
     int accumulate;
+    int kv2;           /* with kv != 0 and c2 != NULL: a COLUMN-SPLIT (combt) layer inside an any-KV launch — stream 1 (columns
+                          [0, k/2)) at kv, stream 2 at kv2 bits, both of the call's S; the call's split stays NONE.  tcomb and
+                          tcq projections of a mixed-scheme model then share one launch.  0: single stream */
 } qpal_tcq_job;
 /* prezero/prezero_bytes (may be NULL/0): a buffer this launch also fills with zeros, for a LATER launch on the
  * same stream that accumulates into it with atomics (split-K of a few-rows x long-K layer such as down_proj).

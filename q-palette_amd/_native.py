@@ -21,7 +21,7 @@ class TcqJob(ctypes.Structure):
                 ("out_zeroed", _I), ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long),
                 ("x_had", _I), ("x_post", _F), ("x_su", _P), ("kv", _I),
                 ("x_f32", _P), ("x_f32_scale", _F), ("x_fresh", _I), ("publish", _I),
-                ("x_rms_eps", _F), ("x_rms_w", _P), ("accumulate", _I)]
+                ("x_rms_eps", _F), ("x_rms_w", _P), ("accumulate", _I), ("kv2", _I)]
 
 
 class LutJob(ctypes.Structure):

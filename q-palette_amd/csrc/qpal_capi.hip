@@ -315,9 +315,12 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
     for (int j = 0; j < njobs; j++) {
         const qpal_tcq_job &jb = jobs[j];
         const int kv = jb.kv ? jb.kv : KV1;
-        mixed = mixed || kv != KV1;
-        if (kv != KV1 && (split != QPAL_SPLIT_NONE || jb.x_had)) return QPAL_E_PARAM;
-        int rc = tcq_check(jb.c1, jb.c2, jb.tlut, jb.m, jb.k, S, kv, KV2, split);
+        const bool job_two = split == QPAL_SPLIT_NONE && jb.kv && jb.kv2 && jb.c2;  // column-split layer in an any-KV launch
+        mixed = mixed || kv != KV1 || job_two;
+        if ((kv != KV1 || job_two) && (split != QPAL_SPLIT_NONE || jb.x_had)) return QPAL_E_PARAM;
+        if (jb.kv2 && !job_two) return QPAL_E_PARAM;
+        int rc = job_two ? tcq_check(jb.c1, jb.c2, jb.tlut, jb.m, jb.k, S, kv, jb.kv2, QPAL_SPLIT_COLS)
+                         : tcq_check(jb.c1, jb.c2, jb.tlut, jb.m, jb.k, S, kv, KV2, split);
         if (rc) return rc;
         if (!jb.out || (!jb.x && !(jb.x_f32 && jb.x_had))) return QPAL_E_NULL;
         if (jb.x_f32 && !jb.x_had) return QPAL_E_PARAM;  // fp32 input: rotation staging (or chain launches) only
@@ -325,12 +328,13 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         if (jb.wscale && !aligned(jb.wscale, 2)) return QPAL_E_ALIGN;
         if (jb.ldo != 0 && jb.ldo < jb.m) return QPAL_E_SHAPE;
         const long ldo = jb.ldo ? jb.ldo : jb.m;
-        if (split == QPAL_SPLIT_NONE)
+        if (split == QPAL_SPLIT_NONE && !job_two)
             tcq_fill(mp.job[j], jb.out, ldo, jb.c1, nullptr, jb.x, jb.tlut, jb.m, n, jb.k, jb.k, 0, jb.wscale, jb.oscale);
         else
             tcq_fill(mp.job[j], jb.out, ldo, jb.c1, jb.c2, jb.x, jb.tlut, jb.m, n, jb.k, jb.k / 2, jb.k / 2, jb.wscale,
                      jb.oscale);
         mp.job[j].kv = kv;
+        mp.job[j].kv2 = job_two ? jb.kv2 : 0;
         rc = set_rotation(mp.job[j], jb.x_had, jb.x_su, jb.x_post, n, jb.k, jb.x_f32, jb.x_rms_eps, jb.x_rms_w);
         if (rc) return rc;
         mp.job[j].accumulate = jb.accumulate ? 1 : 0;
@@ -346,8 +350,8 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
     if (mixed) {
         if (n > 8) return QPAL_E_SHAPE;
         for (int j = 0; j < njobs; j++) {
-            const int kv = mp.job[j].kv;
-            if ((S == 9 && kv > 8) || (S == 10 && kv < 8) || (S == 11 && kv < 9)) return QPAL_E_PARAM;
+            for (const int kv : {mp.job[j].kv, mp.job[j].kv2})
+                if (kv && ((S == 9 && kv > 8) || (S == 10 && kv < 8) || (S == 11 && kv < 9))) return QPAL_E_PARAM;
         }
     }
     mp.zero = static_cast<u32x4 *>(prezero);

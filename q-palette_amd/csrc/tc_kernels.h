@@ -54,6 +54,7 @@ struct TcParams {
     int base1, rem1;    // stream 1: st1 = nc1*base1 + rem1 (first rem1 chunks get one more step)
     int base2, rem2;    // stream 2: st2 = (nchunk-nc1)*base2 + rem2
     int kv;                  // TcqAny kernels only: this job's KV (trellis dwords per lane)
+    int kv2;                 // TcqAny kernels only: KV of stream 2 of a column-split (combt) job, 0: single stream
     const uint16_t *x_su;    // gemv prologue rotation (x_rot != 0): fp16 [k] sign vector or null
     float x_pre, x_post;     //   staged x = fp16( fp16( H_k (x * su) * x_pre ) * x_post ), x_pre = k^-1/2
     int x_rot;               //   0: x is used as given; else k / 1024 (k in {2048, 4096}), needs x_lds
@@ -532,16 +533,20 @@ __global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const u
             wraw = p.wscale[((rg << log2_rpw) + (tid >> 5)) * 32 + (tid & 31)];
         const int c = ks * wpr + wr;
         // chunk c -> (stream, [s0, s1)): chunk j of a stream covers base steps, the first rem chunks one more
-        const bool on2 = TWO && c >= p.nc1;
+        // (any-KV kernels take column-split jobs too: the two streams are two KV of the same codebook size, and the waves of a
+        // row pick their decode loop by the stream their chunk lies in — a wave-uniform choice)
+        constexpr bool ANY = is_any_v<C1>;
+        const bool on2 = (TWO || (ANY && p.kv2 != 0)) && c >= p.nc1;
         const int cc = on2 ? c - p.nc1 : c;
         const int base = on2 ? p.base2 : p.base1, rem = on2 ? p.rem2 : p.rem1;
         int s0 = cc * base + (cc < rem ? cc : rem);
         int s1 = s0 + base + (cc < rem ? 1 : 0);
         if (!live) s0 = s1 = 0;
-        constexpr bool ANY = is_any_v<C1>;
         const int nw1 = ANY ? p.kv : C1::NW;  // dwords per lane per supertile of stream 1
+        const int nw2 = ANY ? p.kv2 : CB::NW;
+        const bool two_rt = TWO || (ANY && p.kv2 != 0);
         const StreamView sv1{p.c1 + (long)(live ? sr : 0) * p.nsc1 * 16 * nw1, p.nsc1, 0};
-        const StreamView sv2{TWO ? p.c2 + (long)(live ? sr : 0) * p.nsc2 * 16 * CB::NW : p.c1, TWO ? p.nsc2 : p.nsc1,
+        const StreamView sv2{two_rt ? p.c2 + (long)(live ? sr : 0) * p.nsc2 * 16 * nw2 : p.c1, two_rt ? p.nsc2 : p.nsc1,
                              p.col2};
         Acc<NBG> acc;
         static_for<0, NBG>([&](auto bc) {
@@ -552,9 +557,9 @@ __global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const u
 
         // first step's weights are in flight while x and the codebook image are (re)staged
         if constexpr (ANY) {
-            dispatch_kv<C1::S_>(p.kv, [&](auto kc) {
+            dispatch_kv<C1::S_>(on2 ? p.kv2 : p.kv, [&](auto kc) {
                 constexpr int KVr = decltype(kc)::value;
-                load_step_w<KVr>(sv1, s0, lane, reinterpret_cast<uint32_t(&)[KVr]>(w.a));
+                load_step_w<KVr>(on2 ? sv2 : sv1, s0, lane, reinterpret_cast<uint32_t(&)[KVr]>(w.a));
             });
         } else {
             if (on2) load_step_w<CB::NW>(sv2, s0, lane, w.b);
@@ -679,12 +684,13 @@ __global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const u
         }
         QPAL_STAMP(3);
         if constexpr (ANY) {
-            dispatch_kv<C1::S_>(p.kv, [&](auto kc) {
+            dispatch_kv<C1::S_>(on2 ? p.kv2 : p.kv, [&](auto kc) {
                 constexpr int KVr = decltype(kc)::value;
                 using CK = TcqCodec<C1::S_, KVr>;
                 auto &wk = reinterpret_cast<uint32_t(&)[KVr]>(w.a);
-                if (NBG == 1 && x_lds) gemv_run<CK, true, NBG>(wk, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-                else gemv_run<CK, false, NBG>(wk, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                const StreamView &sv = on2 ? sv2 : sv1;
+                if (NBG == 1 && x_lds) gemv_run<CK, true, NBG>(wk, lut, laneoff, sv, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else gemv_run<CK, false, NBG>(wk, lut, laneoff, sv, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
             });
         } else
         if constexpr (NBG == 1) {

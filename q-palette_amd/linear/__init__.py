@@ -61,12 +61,14 @@ def _codec_key(layer):
 
 
 def _launch_key(layer, mixed_kv):
-    """Key of the launch a layer can join.  mixed_kv: single-stream TCQ layers of one codebook size share a launch
-    whatever their KV (any-KV kernel: KV 2..8 at S = 9, 8..10 at S = 10, 9..10 at S = 11; fused batch <= 8)."""
+    """Key of the launch a layer can join.  mixed_kv: TCQ layers of one codebook size — single-stream and column-split
+    (tcomb) ones — share a launch whatever their KV (any-KV kernel: KV 2..8 at S = 9, 8..10 at S = 10, 9..10 at S = 11;
+    fused batch <= 8)."""
     key = _codec_key(layer)
-    if mixed_kv and key[0] == "tcq":
-        s, kv = layer.tlut_bits, layer.KV
-        if (s == 9 and kv <= 8) or (s == 10 and kv >= 8) or (s == 11 and kv >= 9):
+    if mixed_kv and key[0] in ("tcq", "tcombt"):
+        s = layer.tlut_bits
+        kvs = [layer.KV] if key[0] == "tcq" else list(layer.KV)
+        if all((s == 9 and kv <= 8) or (s == 10 and kv >= 8) or (s == 11 and kv >= 9) for kv in kvs):
             return ("tcq", key[1], s, "any")
     return key
 
@@ -126,9 +128,12 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
         ws = [wscales[i] for i in idxs] if wscales is not None else None
         extra = dict(outs=o, outs_zeroed=outs_zeroed, prezero=prezero, wscales=ws, oscale=oscale, x_rot=x_rot, x_rms=x_rms,
                      accumulate=accumulate)
-        if kind == "tcq":
-            ys = ops.tcq_gemv_multi([(l.trellis, None, l.tlut, l.out_features, l.KV) for l in grp], x2, first.tlut_bits,
-                                    first.KV, **extra)
+        if kind == "tcq" or (kind == "tcombt" and any(_codec_key(l) != _codec_key(first) for l in grp)):
+            # one codec: its own kernel; different KV / single- and two-stream layers mixed: the any-KV kernel (per-job KV)
+            jobs = [(l.trellis, None, l.tlut, l.out_features, l.KV) if isinstance(l, QTIPLinearTCQ)
+                    else (l.trellis1, l.trellis2, l.tlut, l.out_features, l.KV[0], l.KV[1]) for l in grp]
+            kv1 = first.KV if isinstance(first, QTIPLinearTCQ) else first.KV[0]
+            ys = ops.tcq_gemv_multi(jobs, x2, first.tlut_bits, kv1, **extra)
             prezero = None
         elif kind == "tcombt":
             ys = ops.tcq_gemv_multi([(l.trellis1, l.trellis2, l.tlut, l.out_features) for l in grp], x2,

@@ -296,8 +296,8 @@ def _rms_args(x_rms, k):
 def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=False, prezero=None, wscales=None,
                    oscale=1.0, x_rot=None, x_rms=None, accumulate=False):
     """Several TCQ GEMVs of one codec and one input in ONE launch (C-ABI qpal_tcq_gemv_multi).
-    streams: list of (c1, c2_or_None, tlut, m) or (c1, None, tlut, m, KV): with per-stream KV, single-stream layers of one
-    codebook size but different bit widths share the launch.  x: [n, k].  Returns the list of fp32 [n, m] outputs.
+    streams: list of (c1, c2_or_None, tlut, m), (c1, None, tlut, m, KV) or (c1, c2, tlut, m, KV, KV2): with per-stream KV, layers of
+    one codebook size but different bit widths — single-stream and column-split (combt) ones — share the launch.  x: [n, k].  Returns the list of fp32 [n, m] outputs.
     outs: write into these tensors (outs_zeroed: they are all zeros already); prezero: a tensor this launch
     also zeroes for a later split-K launch on the same stream.
     wscales / oscale: fused epilogue out = acc * wscales[j][row] * oscale (the incoherent wrappers' Wscale * scale).
@@ -313,10 +313,16 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
     for j, stream in enumerate(streams):
         c1, c2, tlut, m = stream[:4]
         kv = stream[4] if len(stream) > 4 else 0
+        kv2 = stream[5] if len(stream) > 5 else 0
         c1 = _dev(c1, "compressed1")
         tl = _dev(tlut, "codebook")
         _chk(tl.dtype == torch.float16 and tl.numel() == 2 << S, f"codebook must be fp16 with {2 << S} elements")
-        if split == 0:
+        if split == 0 and kv2:  # a column-split (combt) layer inside an any-KV launch
+            _chk(kv != 0 and c2 is not None, "per-stream KV2 needs KV and the second stream")
+            c2 = _dev(c2, "compressed2")
+            _tcq_stream_ok(c1, m, k // 2, kv, "compressed1")
+            _tcq_stream_ok(c2, m, k // 2, kv2, "compressed2")
+        elif split == 0:
             _tcq_stream_ok(c1, m, k, kv or KV1, "compressed")
         else:
             c2 = _dev(c2, "compressed2")
@@ -327,7 +333,7 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
                              xh.data_ptr() if xh is not None else None, tl.data_ptr(), m, k,
                              1 if (outs is not None and outs_zeroed) else 0,
                              _wscale_arg(wscales, j, m), float(oscale), _ldo(out, n, m), had, xpost, xsu, kv,
-                             x32.data_ptr() if x32 is not None else None, 1.0, 0, 0, rms_eps, rms_w, 1 if accumulate else 0)
+                             x32.data_ptr() if x32 is not None else None, 1.0, 0, 0, rms_eps, rms_w, 1 if accumulate else 0, kv2)
         results.append(out)
         keep += [c1, c2, tl]
     zp, zb = _prezero_args(prezero)

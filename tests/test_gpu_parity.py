@@ -426,6 +426,43 @@ def test_mixed_kv_projections_share_one_launch(qp, oracle):
             assert torch.allclose(y, mod._gemv(x, 12), rtol=1e-4, atol=1e-4 * float(y.abs().max()))
 
 
+def test_tcomb_and_tcq_projections_share_one_launch(qp, oracle):
+    """Mixed-scheme q | k | v where some projections are column-split (tcomb_x_y: two streams, two bit widths) and some plain
+    TCQ: one any-KV launch (per-job KV and KV2; the waves of a row pick their decode loop by the stream their chunk lies in),
+    equal to the layers' own launches and to the oracle.  A pair the any-KV kernel cannot hold (KV2 = 9 at S = 9) stays apart."""
+    k = 4096
+    cases = ((("tcomb_3_4_0.5_none_0.9", "tcq_6_none_0.9", "tcq_3_none_0.9"), (4096, 1024, 1024)),
+             (("tcomb_6_7_0.5_none_0.9", "tcomb_2_3_0.5_none_0.9"), (14336, 14336)),
+             (("tcq_5_none_0.9", "tcomb_7_8_0.5_none_0.9", "tcomb_4_5_0.5_none_0.9", "tcq_8_none_0.9"), (512, 2048, 96, 32)))
+    for qstrs, ms in cases:
+        layers = []
+        for i, (qstr, m) in enumerate(zip(qstrs, ms)):
+            info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=200 + i, codebook_seed=3)
+            layers.append((qp.make_linear_from_info(qstr, info).cuda(), qstr, info))
+        mods = [l for l, _, _ in layers]
+        qp.share_codebooks(mods)
+        assert [len(g) for g in qp.linear.launch_groups(mods, mixed_kv=True)] == [len(mods)], qstrs
+        for n in (1, 5, 8):
+            x = torch.randn(n, k, generator=torch.Generator().manual_seed(40 + n)).cuda()
+            ys = qp.multi_gemv(mods, x)
+            for (mod, qstr, info), y, m in zip(layers, ys, ms):
+                ref = mod._gemv(x, n)
+                assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max())), (qstrs, qstr, n)
+                if n != 8:
+                    _check_gemv(y.cpu().numpy(), _oracle_weight(oracle, qstr, info, m, k), x.half().cpu().numpy(), oracle)
+        # fused epilogue and a pre-zeroed split-K output through the same launch
+        x = torch.randn(1, k, generator=torch.Generator().manual_seed(7)).cuda()
+        wsc = [(0.5 + torch.rand(m, generator=torch.Generator().manual_seed(m))).half().cuda() for m in ms]
+        outs = [torch.zeros(1, m, device="cuda") for m in ms]
+        ys = qp.multi_gemv(mods, x, outs=outs, outs_zeroed=True, wscales=wsc, oscale=0.25)
+        for (mod, _, _), y, w in zip(layers, ys, wsc):
+            ref = mod._gemv(x, 1) * w.float() * 0.25
+            assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    info = qp.mem_op.dummy_linear_info(k, 256, "tcomb_8_9_0.5_none_0.9", seed=1, codebook_seed=3)
+    far = qp.make_linear_from_info("tcomb_8_9_0.5_none_0.9", info).cuda()
+    assert sorted(len(g) for g in qp.linear.launch_groups([mods[0], far], mixed_kv=True)) == [1, 1]
+
+
 class _RefStyleTCQ(torch.nn.Module):
     """The reference's QTIPLinearTCQ.forward pattern (lib/linear/tcq_linear.py:64-85): op looked up by name inside forward."""
 
