@@ -134,6 +134,15 @@ typedef struct qpal_lut_job {
 int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits, int vec, void *prezero,
                            long prezero_bytes, void *stream);
 
+/* Jobs of DIFFERENT FAMILIES in one launch: TCQ layers of codebook size S (every job carries its own kv, column-split layers
+ * also kv2: see qpal_tcq_job) next to VQ/SQ layers in tensor-core packing (lut_bits[i], lut_vec[i] for lut_jobs[i]) whose
+ * codebook image is no larger than the TCQ one: vec 2 with 2..8 bits, vec 1 with 2, 3, 4, 7, 8 bits.  What q | k | v of a
+ * mixed-scheme model (the reference's MSQ results give every projection its own quantizer) need to stay ONE launch.  Outputs,
+ * epilogue fields, ldo, out_zeroed and prezero as in the single-family calls; n <= 8; no fused rotation (x_had = 0).
+ * ntcq may be 0 (VQ/SQ layers of different codecs); nlut >= 1; ntcq + nlut <= 8.                                          */
+int qpal_mixed_gemv_multi(const qpal_tcq_job *tcq_jobs, int ntcq, const qpal_lut_job *lut_jobs, int nlut, const int *lut_bits,
+                          const int *lut_vec, int n, int S, void *prezero, long prezero_bytes, void *stream);
+
 /* Chains: a sequence of DEPENDENT multi-job GEMV launches of ONE codec and batch (phase p+1 may consume what phase p
  * wrote) executed by ONE persistent launch — q|k|v -> o -> gate|up -> down -> the next block's q|k|v ... of a decoded
  * token.  Stream order between the phases is kept by an in-kernel arrival counter; what does not depend on the

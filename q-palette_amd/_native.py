@@ -45,6 +45,8 @@ PEER_WS_BYTES_PER_SLOT = 256
 _SIGNATURES = {
     "qpal_tcq_gemv_multi": [ctypes.POINTER(TcqJob), _I, _I, _I, _I, _I, _I, _P, ctypes.c_long, _P],
     "qpal_lut_tc_gemv_multi": [ctypes.POINTER(LutJob), _I, _I, _I, _I, _P, ctypes.c_long, _P],
+    "qpal_mixed_gemv_multi": [ctypes.POINTER(TcqJob), _I, ctypes.POINTER(LutJob), _I, ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _I, _P,
+                              ctypes.c_long, _P],
     "qpal_tcq_gemv": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "qpal_tcq_dequant": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "qpal_lut_tc_gemv": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

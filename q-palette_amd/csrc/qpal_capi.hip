@@ -479,6 +479,71 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
     return launch_lut_tc_gemv(mp, bits, vec, nbg, grid, s);
 }
 
+int qpal_mixed_gemv_multi(const qpal_tcq_job *tcq_jobs, int ntcq, const qpal_lut_job *lut_jobs, int nlut, const int *lut_bits,
+                          const int *lut_vec, int n, int S, void *prezero, long prezero_bytes, void *stream) {
+    if ((ntcq > 0 && !tcq_jobs) || (nlut > 0 && (!lut_jobs || !lut_bits || !lut_vec))) return QPAL_E_NULL;
+    if (ntcq < 0 || nlut < 1 || ntcq + nlut > kMaxJobs) return QPAL_E_SHAPE;
+    if (prezero_bytes < 0 || prezero_bytes % 16 || (prezero_bytes && (!prezero || !aligned(prezero, 16)))) return QPAL_E_ALIGN;
+    if (n < 1 || n > 8) return QPAL_E_SHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TcMultiParams mp{};
+    mp.njobs = ntcq + nlut;
+    int zeroed[kMaxJobs] = {0};
+    int ms[kMaxJobs] = {0};
+    const void *x0 = nullptr;
+    int k0 = 0;
+    for (int j = 0; j < ntcq; j++) {
+        const qpal_tcq_job &jb = tcq_jobs[j];
+        if (!jb.kv || jb.x_had || jb.x_f32 || jb.accumulate) return QPAL_E_PARAM;  // per-job KV; no fused rotation here
+        const bool two = jb.kv2 && jb.c2;
+        if (jb.kv2 && !two) return QPAL_E_PARAM;
+        int rc = two ? tcq_check(jb.c1, jb.c2, jb.tlut, jb.m, jb.k, S, jb.kv, jb.kv2, QPAL_SPLIT_COLS)
+                     : tcq_check(jb.c1, nullptr, jb.tlut, jb.m, jb.k, S, jb.kv, 0, QPAL_SPLIT_NONE);
+        if (rc) return rc;
+        for (const int kv : {jb.kv, jb.kv2})
+            if (kv && ((S == 9 && kv > 8) || (S == 10 && kv < 8) || (S == 11 && kv < 9))) return QPAL_E_PARAM;
+        if (!jb.out || !jb.x) return QPAL_E_NULL;
+        if (!aligned(jb.x, 8) || !aligned(jb.out, 4) || (jb.k % 4) || (jb.wscale && !aligned(jb.wscale, 2))) return QPAL_E_ALIGN;
+        if (jb.ldo != 0 && jb.ldo < jb.m) return QPAL_E_SHAPE;
+        const long ldo = jb.ldo ? jb.ldo : jb.m;
+        if (two) tcq_fill(mp.job[j], jb.out, ldo, jb.c1, jb.c2, jb.x, jb.tlut, jb.m, n, jb.k, jb.k / 2, jb.k / 2, jb.wscale, jb.oscale);
+        else tcq_fill(mp.job[j], jb.out, ldo, jb.c1, nullptr, jb.x, jb.tlut, jb.m, n, jb.k, jb.k, 0, jb.wscale, jb.oscale);
+        mp.job[j].kv = jb.kv;
+        mp.job[j].kv2 = two ? jb.kv2 : 0;
+        zeroed[j] = jb.out_zeroed;
+        ms[j] = jb.m;
+        if (!x0) x0 = jb.x, k0 = jb.k;
+        if (jb.x == x0 && jb.k != k0) return QPAL_E_PARAM;
+    }
+    for (int i = 0; i < nlut; i++) {
+        const qpal_lut_job &jb = lut_jobs[i];
+        const int j = ntcq + i, bits = lut_bits[i], vec = lut_vec[i];
+        if (!mix_lut_ok(bits, vec)) return QPAL_E_PARAM;  // codecs whose image fits the TCQ one (tc_kernels.h QPAL_MIX_LUT_CODECS)
+        if (jb.x_had || jb.x_f32 || jb.accumulate) return QPAL_E_PARAM;
+        int rc = lut_args_ok(jb.out, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k, bits, vec);
+        if (rc) return rc;
+        if (jb.wscale && !aligned(jb.wscale, 2)) return QPAL_E_ALIGN;
+        if (jb.ldo != 0 && jb.ldo < jb.m) return QPAL_E_SHAPE;
+        lut_fill(mp.job[j], jb.out, jb.ldo ? jb.ldo : jb.m, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k, jb.wscale, jb.oscale);
+        mp.job[j].kv = vec == 2 ? bits : 2 * bits;  // dwords per lane and supertile (LutCodec::NW)
+        mp.job[j].lut_bits = bits;
+        mp.job[j].lut_vec = vec;
+        zeroed[j] = jb.out_zeroed;
+        ms[j] = jb.m;
+        if (!x0) x0 = jb.x, k0 = jb.k;
+        if (jb.x == x0 && jb.k != k0) return QPAL_E_PARAM;
+    }
+    mp.zero = static_cast<u32x4 *>(prezero);
+    mp.zero_chunks = (int)(prezero_bytes / 16);
+    int grid;
+    plan_launch(mp, zeroed, grid, waves_of(1));
+    for (int j = 0; j < mp.njobs; j++) {
+        int rc = zero_if_split(mp.job[j], ms[j], s, zeroed[j]);
+        if (rc) return rc;
+    }
+    return launch_tcq_gemv_mix(mp, S, grid, s);
+}
+
 int qpal_lut_tc_dequant(void *out_f16, const void *qweight, const void *lut, int m, int k, int bits, int vec,
                         void *stream) {
     if (!out_f16 || !qweight || !lut) return QPAL_E_NULL;

@@ -55,6 +55,7 @@ struct TcParams {
     int base2, rem2;    // stream 2: st2 = (nchunk-nc1)*base2 + rem2
     int kv;                  // TcqAny kernels only: this job's KV (trellis dwords per lane)
     int kv2;                 // TcqAny kernels only: KV of stream 2 of a column-split (combt) job, 0: single stream
+    int lut_bits, lut_vec;   // TcqMix kernels only: != 0: this job is a VQ/SQ (LutCodec<lut_bits, lut_vec>) layer; kv = its dwords per lane
     const uint16_t *x_su;    // gemv prologue rotation (x_rot != 0): fp16 [k] sign vector or null
     float x_pre, x_post;     //   staged x = fp16( fp16( H_k (x * su) * x_pre ) * x_post ), x_pre = k^-1/2
     int x_rot;               //   0: x is used as given; else k / 1024 (k in {2048, 4096}), needs x_lds
@@ -409,6 +410,33 @@ __device__ __forceinline__ void dispatch_kv(int kv, F &&f) {
     });
 }
 
+// Mixed-FAMILY launches: a mixed-scheme model's q | k | v are often TCQ and VQ/SQ layers side by side.  TcqMix<S> = TcqAny<S>
+// whose job table may also hold VQ/SQ (tensor-core packing) jobs of the codecs below — those whose image is no larger than
+// the TCQ one, so the LDS allocation is unchanged; a workgroup builds the image of the job it works on and switches to that
+// family's decode loop (workgroup-uniform; the instruction cache of a CU only ever sees the loops of the jobs it runs).
+template <int S>
+struct TcqMix : TcqAny<S> {
+    static constexpr bool kMix = true;
+    static constexpr int NW = 16;  // registers for the widest member: LutCodec<8, 1>
+};
+template <class C>
+constexpr bool is_mix_v = requires { C::kMix; };
+
+#define QPAL_MIX_LUT_CODECS(X) X(2, 2) X(3, 2) X(4, 2) X(5, 2) X(6, 2) X(7, 2) X(8, 2) X(2, 1) X(3, 1) X(4, 1) X(7, 1) X(8, 1)
+inline bool mix_lut_ok(int bits, int vec) {
+#define QPAL_X(B_, V_) if (bits == B_ && vec == V_) return true;
+    QPAL_MIX_LUT_CODECS(QPAL_X)
+#undef QPAL_X
+    return false;
+}
+// f(LutCodec<bits, vec>{}) for the runtime (bits, vec) of a job (uniform across the workgroup)
+template <class F>
+__device__ __forceinline__ void dispatch_lut(int bits, int vec, F &&f) {
+#define QPAL_X(B_, V_) if (bits == B_ && vec == V_) f(LutCodec<B_, V_>{});
+    QPAL_MIX_LUT_CODECS(QPAL_X)
+#undef QPAL_X
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused decode + GEMV / skinny GEMM, 1 <= n <= 8*NBG.  1024 threads (16 waves, 4 per SIMD), one workgroup per
 // CU (LDS-bound).  C2 == void: single stream.  Otherwise combt (columns [0,col2) from c1 via C1, the rest from
@@ -556,11 +584,21 @@ __global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const u
         });
 
         // first step's weights are in flight while x and the codebook image are (re)staged
+        bool lut_job = false;  // workgroup-uniform
+        if constexpr (is_mix_v<C1>) lut_job = p.lut_bits != 0;
         if constexpr (ANY) {
-            dispatch_kv<C1::S_>(on2 ? p.kv2 : p.kv, [&](auto kc) {
-                constexpr int KVr = decltype(kc)::value;
-                load_step_w<KVr>(on2 ? sv2 : sv1, s0, lane, reinterpret_cast<uint32_t(&)[KVr]>(w.a));
-            });
+            if constexpr (is_mix_v<C1>) {
+                if (lut_job)
+                    dispatch_lut(p.lut_bits, p.lut_vec, [&](auto cc) {
+                        using CL = decltype(cc);
+                        load_step_w<CL::NW>(sv1, s0, lane, reinterpret_cast<uint32_t(&)[CL::NW]>(w.a));
+                    });
+            }
+            if (!lut_job)
+                dispatch_kv<C1::S_>(on2 ? p.kv2 : p.kv, [&](auto kc) {
+                    constexpr int KVr = decltype(kc)::value;
+                    load_step_w<KVr>(on2 ? sv2 : sv1, s0, lane, reinterpret_cast<uint32_t(&)[KVr]>(w.a));
+                });
         } else {
             if (on2) load_step_w<CB::NW>(sv2, s0, lane, w.b);
             else load_step_w<C1::NW>(sv1, s0, lane, w.a);
@@ -676,7 +714,18 @@ __global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const u
                 cur_x = p.x;
             }
             if (p.tab != cur_tab) {
-                C1::build(lut, p.tab, tid, NT);
+                bool built = false;
+                if constexpr (is_mix_v<C1>) {
+                    if (p.lut_bits) {
+                        dispatch_lut(p.lut_bits, p.lut_vec, [&](auto cc) {
+                            using CL = decltype(cc);
+                            static_assert(CL::LDS_DWORDS <= C1::LDS_DWORDS, "a mixed launch keeps the TCQ image's LDS allocation");
+                            CL::build(lut, p.tab, tid, NT);
+                        });
+                        built = true;
+                    }
+                }
+                if (!built) C1::build(lut, p.tab, tid, NT);
                 cur_tab = p.tab;
             }
             QPAL_STAMP(2);
@@ -684,6 +733,17 @@ __global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const u
         }
         QPAL_STAMP(3);
         if constexpr (ANY) {
+            if constexpr (is_mix_v<C1>) {
+                if (lut_job)
+                    dispatch_lut(p.lut_bits, p.lut_vec, [&](auto cc) {
+                        using CL = decltype(cc);
+                        auto &wk = reinterpret_cast<uint32_t(&)[CL::NW]>(w.a);
+                        const uint32_t lo = (uint32_t)(lane & (CL::C - 1)) << 2;
+                        if (NBG == 1 && x_lds) gemv_run<CL, true, NBG>(wk, lut, lo, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                        else gemv_run<CL, false, NBG>(wk, lut, lo, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                    });
+            }
+            if (!lut_job)
             dispatch_kv<C1::S_>(on2 ? p.kv2 : p.kv, [&](auto kc) {
                 constexpr int KVr = decltype(kc)::value;
                 using CK = TcqCodec<C1::S_, KVr>;

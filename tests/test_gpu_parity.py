@@ -463,6 +463,46 @@ def test_tcomb_and_tcq_projections_share_one_launch(qp, oracle):
     assert sorted(len(g) for g in qp.linear.launch_groups([mods[0], far], mixed_kv=True)) == [1, 1]
 
 
+def test_tcq_and_vq_sq_projections_share_one_launch(qp, oracle, monkeypatch):
+    """Mixed-FAMILY q | k | v (the reference's MSQ results give every projection its own quantizer): TCQ layers of any KV,
+    column-split tcomb layers and VQ/SQ tensor-core-packing layers with small codebook images go out as ONE launch
+    (qpal_mixed_gemv_multi: the workgroup builds the image of the job it works on and runs that family's decode loop); VQ/SQ
+    layers of different codecs without a TCQ neighbour share a launch too; wide codebooks stay on their own.  (Opt-in:
+    QPAL_MIXED_FAMILY=1 — measured slower than separate launches on the published models)"""
+    monkeypatch.setenv("QPAL_MIXED_FAMILY", "1")
+    k = 4096
+    cases = ((("tcq_3_none_0.9", "ldlq_2_6_none_1.0", "tcomb_4_5_0.5_none_0.9"), (4096, 1024, 1024), [3]),
+             (("ldlq_2_8_none_1.0", "tcq_7_none_0.9", "ldlq_1_4_none_1.0", "ldlq_1_8_none_1.0", "tcomb_6_7_0.5_none_0.9"),
+              (14336, 512, 4096, 96, 2048), [5]),
+             (("ldlq_2_3_none_1.0", "ldlq_1_7_none_1.0", "ldlq_2_5_none_1.0"), (1024, 1024, 4096), [3]),
+             (("tcq_4_none_0.9", "ldlq_2_10_none_1.0", "ldlq_1_6_none_1.0", "ldlq_2_4_none_1.0"), (1024, 512, 512, 256), [1, 1, 2]))
+    for qstrs, ms, want_sizes in cases:
+        layers = []
+        for i, (qstr, m) in enumerate(zip(qstrs, ms)):
+            info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=300 + i, codebook_seed=3)
+            layers.append((qp.make_linear_from_info(qstr, info).cuda(), qstr, info))
+        mods = [l for l, _, _ in layers]
+        qp.share_codebooks(mods)
+        assert sorted(len(g) for g in qp.linear.launch_groups(mods, mixed_kv=True)) == want_sizes, qstrs
+        for n in (1, 4, 8):
+            x = torch.randn(n, k, generator=torch.Generator().manual_seed(60 + n)).cuda()
+            ys = qp.multi_gemv(mods, x)
+            for (mod, qstr, info), y, m in zip(layers, ys, ms):
+                ref = mod._gemv(x, n)
+                assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max())), (qstrs, qstr, n)
+                if n == 4:
+                    _check_gemv(y.cpu().numpy(), _oracle_weight(oracle, qstr, info, m, k), x.half().cpu().numpy(), oracle)
+        x = torch.randn(1, k, generator=torch.Generator().manual_seed(9)).cuda()
+        wsc = [(0.5 + torch.rand(m, generator=torch.Generator().manual_seed(m))).half().cuda() for m in ms]
+        buf = torch.zeros(1, sum(ms), device="cuda")
+        spare = torch.full((1, 4096), 7.0, device="cuda")
+        ys = qp.multi_gemv(mods, x, outs=list(buf.split(list(ms), dim=1)), outs_zeroed=True, wscales=wsc, oscale=0.25, prezero=spare)
+        assert float(spare.abs().max()) == 0.0
+        for (mod, _, _), y, w in zip(layers, ys, wsc):
+            ref = mod._gemv(x, 1) * w.float() * 0.25
+            assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+
+
 class _RefStyleTCQ(torch.nn.Module):
     """The reference's QTIPLinearTCQ.forward pattern (lib/linear/tcq_linear.py:64-85): op looked up by name inside forward."""
 
