@@ -6,9 +6,10 @@ Host-side mirror of the reference's lib/utils/matmul_had.py for the functions on
 to the third-party fast_hadamard_transform).  Differences by design:
 
 * the reference ships its K x K Hadamard factors as 95 k lines of literals; here the ones with a classical
-  construction are GENERATED (Paley I for K = 12, 20, 60, 108, 140; Paley II for K = 28, 36) and checked
-  entry for entry against ``get_hadK`` outputs in tests/golden/hadamard.npz.  K = 52, 116, 124, 156, 172 (Llama-1/2
-  and Falcon sizes, no Llama-3 layer) have no closed form: ``register_hadK`` accepts the matrix from the caller;
+  are GENERATED — Paley I for K = 12, 20, 60, 108, 140, Paley II for K = 28, 36, and Williamson arrays of four
+  symmetric circulants for K = 52, 116, 124, 156, 172 (the reference's literals turn out to be exactly that: the four
+  first rows, K bits per matrix, are the only constants kept) — and checked entry for entry against ``get_hadK``
+  outputs in tests/golden/hadamard.npz; ``register_hadK`` accepts any other factor from the caller;
 * sign flip, both Hadamard factors, the scales and (optionally) SwiGLU run in ONE launch (``rotate``).
 """
 import math
@@ -20,6 +21,15 @@ from . import _native
 IN_F16, IN_F32, IN_SWIGLU_F32 = 0, 1, 2
 
 _PALEY = {12: (1, 11), 20: (1, 19), 28: (2, 13), 36: (2, 17), 60: (1, 59), 108: (1, 107), 140: (1, 139)}
+# Williamson arrays [[A, B, C, D], [-B, A, -D, C], [-C, D, A, -B], [-D, -C, B, A]]: first rows of the circulants A, B, C, D
+# (bit i from the top = element i; 1 = +1), found by analysing the reference's get_had52 .. get_had172 outputs
+_WILLIAMSON = {
+    52: (0x14f2, 0x11f8, 0x1a65, 0x1090),
+    116: (0x192ef749, 0x1ed1f8b7, 0x1465fa62, 0x1c650a63),
+    124: (0x4e90c25c, 0x4e90c25c, 0x41d4cae0, 0x7e2b351f),
+    156: (0x7282619053, 0x7898528647, 0x73452128b3, 0x46a0edc158),
+    172: (0x467aecdd798, 0x6fc29b650fd, 0x7595e85ea6b, 0x63d260192f1),
+}
 # precedence of the reference's get_hadK (a size divisible by several K takes the first)
 _ORDER = (172, 156, 140, 124, 116, 108, 60, 52, 36, 28, 20, 12)
 _registered = {}
@@ -51,8 +61,20 @@ def _paley(kind, q):
     return torch.cat([torch.cat([core + eye, core - eye], 1), torch.cat([core - eye, -core - eye], 1)], 0)
 
 
+def _williamson(K, seeds):
+    q = K // 4
+    idx = torch.arange(q)
+    blocks = []
+    for seed in seeds:
+        row = torch.tensor([1.0 if (seed >> (q - 1 - i)) & 1 else -1.0 for i in range(q)])
+        blocks.append(row[(idx[None, :] - idx[:, None]) % q])  # circulant: row r = first row rotated right by r
+    a, b, c, d = blocks
+    return torch.cat([torch.cat([a, b, c, d], 1), torch.cat([-b, a, -d, c], 1), torch.cat([-c, d, a, -b], 1),
+                      torch.cat([-d, -c, b, a], 1)], 0)
+
+
 def register_hadK(K, matrix):
-    """Supply a K x K +-1 Hadamard factor the build cannot construct (K = 52, 116, 124, 156, 172)."""
+    """Supply a K x K +-1 Hadamard factor the build does not construct itself."""
     m = torch.as_tensor(matrix, dtype=torch.float32)
     if m.shape != (K, K) or not bool((m.abs() == 1).all()) or not torch.equal(m @ m.T, K * torch.eye(K)):
         raise ValueError(f"not a {K}x{K} Hadamard matrix")
@@ -66,8 +88,10 @@ def hadK_matrix(K):
             _cache[K] = _registered[K]
         elif K in _PALEY:
             _cache[K] = _paley(*_PALEY[K])
+        elif K in _WILLIAMSON:
+            _cache[K] = _williamson(K, _WILLIAMSON[K])
         else:
-            raise NotImplementedError(f"no built-in {K}x{K} Hadamard factor: pass the reference's matrix to "
+            raise NotImplementedError(f"no built-in {K}x{K} Hadamard factor: pass one to "
                                       f"qpalette_amd.hadamard.register_hadK({K}, matrix)")
     return _cache[K]
 

@@ -144,17 +144,17 @@ def gen_tc_to_simt(rng, m, k, bits, vec):
 
 def gen_hadamard():
     """get_hadK sign matrices and matmul_hadU / matmul_hadUt outputs (float64) for the block sizes the build
-    constructs itself (K = 1, 12, 20, 28, 36, 60) at small n, plus the two Llama-3.1-8B sizes."""
+    constructs itself at small n, plus the two Llama-3.1-8B sizes and Llama-2-7B's 11008 = 172 * 64."""
     from lib.utils.matmul_had import get_hadK, matmul_hadU, matmul_hadUt
     rng = np.random.default_rng(20251011)
     out = {}
-    for K in (12, 20, 28, 36, 60, 108, 140):
+    for K in (12, 20, 28, 36, 60, 108, 140, 52, 116, 124, 156, 172):
         hadK, kk = get_hadK(K * 16)
         assert kk == K
         h = hadK.numpy()
         assert np.all(np.abs(h) == 1)
         out[f"hadK_{K}"] = np.packbits(h > 0, axis=1)          # sign bits, row-major
-    sizes = [64, 128, 12 * 16, 20 * 32, 28 * 16, 36 * 16, 60 * 16, 4096, 14336]
+    sizes = [64, 128, 12 * 16, 20 * 32, 28 * 16, 36 * 16, 60 * 16, 4096, 14336, 52 * 16, 172 * 64]
     for n in sizes:
         x = rng.standard_normal((2, n)).astype(np.float32)
         xt = torch.from_numpy(x).to(torch.float64)

@@ -25,7 +25,7 @@ def _gold():
 
 
 # ------------------------------------------------------------------------------------------------ CPU
-@pytest.mark.parametrize("K", [12, 20, 28, 36, 60, 108, 140])
+@pytest.mark.parametrize("K", [12, 20, 28, 36, 60, 108, 140, 52, 116, 124, 156, 172])
 def test_generated_factor_equals_reference(K):
     import qpalette_amd as qp
     ref = oi.unpack_hadk(_gold()[f"hadK_{K}"], K)
@@ -56,8 +56,9 @@ def test_get_hadK_grammar():
     h, _ = had.get_hadK(3072)
     ht, _ = had.get_hadK(3072, transpose=True)
     assert torch.equal(h.T, ht) and not torch.equal(h, ht)  # Paley I factors are not symmetric
+    assert had.get_hadK(11008)[1] == 172 and had.get_hadK(13312)[1] == 52  # Williamson factors (Llama-2-7B / -13B sizes)
     with pytest.raises(NotImplementedError):
-        had.get_hadK(11008)  # 172 * 64: no closed form; register_hadK is the way in
+        had.hadK_matrix(44)  # not one of the reference's factors: register_hadK is the way in
     with pytest.raises(AssertionError):
         had.get_hadK(4097 * 3)
     with pytest.raises(ValueError):
@@ -178,7 +179,8 @@ def _signs(rng, n):
 @pytest.mark.parametrize("rows,n,hd", [(1, 64, 64), (3, 128, 128), (1, 1024, 1024), (1, 4096, 4096), (16, 4096, 4096),
                                        (2, 8192, 8192), (1, 32768, 32768), (1, 14336, 14336), (5, 14336, 14336),
                                        (1, 28672, 28672), (3, 3072, 3072), (2, 5120, 5120), (2, 13824, 13824),
-                                       (4, 4096, 128), (2, 3584, 448), (3, 2048, 64)])
+                                       (4, 4096, 128), (2, 3584, 448), (3, 2048, 64),
+                                       (2, 11008, 11008), (1, 13312, 13312), (1, 7424, 7424), (1, 9984, 9984)])  # K = 172, 52, 116, 156 (Williamson)
 @pytest.mark.parametrize("round_mid", [True, False])
 def test_rotate_vs_oracle(qp, rows, n, hd, round_mid):
     had = qp.hadamard
@@ -209,7 +211,7 @@ def test_rotate_vs_oracle(qp, rows, n, hd, round_mid):
             assert np.all(np.abs(got - want) <= (1.5 * _ulp16(want) + 0.5 * K * extra) * 1.0001)
         else:
             assert np.all(np.abs(got - want) <= (_ulp16(want) + extra) * 1.0001)
-            assert (np.abs(got - want) > _ulp16(want) * 1.0001).mean() < 1e-3  # and it is rare
+            assert (np.abs(got - want) > _ulp16(want) * 1.0001).mean() < 5e-4 + 2e-5 * K  # and it is rare (one chance per term)
     else:
         _assert_ulp(y.cpu().numpy(), want)
 
