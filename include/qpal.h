@@ -258,7 +258,9 @@ int qpal_attn_decode(const void *q_f16, const void *kcache_f16, const void *vcac
  * ws != NULL (qpal_attn_ws_bytes(...) > 0 bytes of device memory, 4-byte aligned, zero-filled ONCE, kept across launches):
  * split-context form for long caches — workgroup (kv head, chunk of the context) serves all nq / nkv query heads of its group,
  * the last workgroup of a kv head to arrive merges the partial softmaxes.  qpal_attn_ws_bytes returns 0 where the split form
- * does not apply (max_len < 2048, nq / nkv not in {1, 2, 4, 8}, (nq / nkv) * hd > 1024): pass ws = NULL then.               */
+ * does not apply (max_len < 2048, nq / nkv not in {1, 2, 4, 8}, (nq / nkv) * hd > 1024): pass ws = NULL then.
+ * *pos outside [0, max_len) (it lives on the device: the host cannot check it): the launch does nothing — no cache row is
+ * written, out is left as it was; the same holds for qpal_rope_kv / qpal_attn_decode.                                   */
 long qpal_attn_ws_bytes(int nq, int nkv, int hd, long max_len);
 int qpal_attn_rope_decode(const float *q, const float *k, const float *v, void *kcache_f16, void *vcache_f16, void *out_f16,
                           const long *pos, const float *inv_freq, int nq, int nkv, int hd, long max_len, float scale,

@@ -23,6 +23,7 @@ struct RopeParams {
 __global__ __launch_bounds__(64) void rope_kv_kernel(const RopeParams p) {
     const int head = blockIdx.x, half = p.hd / 2;
     const long pos = *p.pos;
+    if (pos < 0 || pos >= p.max_len) return;  // a position outside the cache: nothing is written (no out-of-bounds access)
     for (int i = threadIdx.x; i < half; i += 64) {
         if (head < p.nq + p.nkv) {
             const float *src = head < p.nq ? p.q + (long)head * p.hd : p.k + (long)(head - p.nq) * p.hd;
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
     extern __shared__ float sh[];  // scores [max_len] | q [hd] | partial out [4][hd] | reduce [8]
     const int head = blockIdx.x, kh = head / (p.nq / p.nkv), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long len = *p.pos + 1;
+    if (len < 1 || len > p.max_len) return;  // position outside the cache: out is left untouched
     float *sc = sh, *qs = sh + p.max_len, *po = qs + p.hd, *red = po + 4 * p.hd;
     for (int d = tid; d < p.hd; d += 256) qs[d] = (float)__builtin_bit_cast(_Float16, p.q[(long)head * p.hd + d]) * p.scale;
     __syncthreads();
@@ -279,7 +281,9 @@ __device__ __forceinline__ void attn_rope_head(const AttnRopeParams &p, float *s
 template <int HD>
 __global__ __launch_bounds__(1024) void attn_rope_decode_kernel(const AttnRopeParams p) {
     extern __shared__ float sh[];
-    attn_rope_head<HD, 16>(p, sh, blockIdx.x, *p.pos, p.max_len);
+    const long pos = *p.pos;
+    if (pos < 0 || pos >= p.max_len) return;  // position outside the cache: nothing is read or written
+    attn_rope_head<HD, 16>(p, sh, blockIdx.x, pos, p.max_len);
 }
 
 // Split-context form of the above for long caches (flash-decoding shape).  One workgroup per query head streams the whole
@@ -319,6 +323,7 @@ __global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSpli
     const int kh = blockIdx.x / sp.nsplit, split = blockIdx.x - kh * sp.nsplit;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long pos = *p.pos;
+    if (pos < 0 || pos >= p.max_len) return;  // position outside the cache: nothing is read or written, no ticket taken
     // A short context in a long cache: the first nq workgroups run the one-head body, the others leave.  Measured per launch
     // (32 heads, 8 kv heads, hd 128): one-head body 4.9 us at 40 positions, 9.8 at 500, 28.5 at 2000, 62 at 4000, 457 at 32 k;
     // this kernel's group form 12.6 at 500, 16.5 at 2000, 18.4 at 4000, 38 at 32 k (134 MB: 3.5 TB/s) — its floor is the

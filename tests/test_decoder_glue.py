@@ -125,6 +125,37 @@ def test_attn_rope_decode_one_launch_matches_torch(qp, nq, nkv, hd, ctx, pos, sp
     assert torch.allclose(out.view(nq, hd).float(), ref.view(nq, hd), atol=4e-3, rtol=4e-3)
 
 
+@pytest.mark.parametrize("ctx,split", [(256, False), (4096, True)])
+def test_attention_position_outside_the_cache_touches_nothing(qp, ctx, split):
+    """*pos lives on the device, so the host cannot validate it: a position outside [0, max_len) must not write anywhere."""
+    dev = torch.device("cuda", 0)
+    nat = qp._native
+    nq, nkv, hd = 32, 8, 128
+    q32, k32, v32 = (torch.randn(n * hd, device=dev) for n in (nq, nkv, nkv))
+    kc = torch.randn(nkv, ctx, hd, device=dev).half()
+    vc = torch.randn(nkv, ctx, hd, device=dev).half()
+    guard = torch.zeros(2, 4096, dtype=torch.float16, device=dev)  # allocated right after the caches
+    kc0, vc0 = kc.clone(), vc.clone()
+    inv_freq = 1.0 / (500000.0 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
+    out = torch.full((nq * hd,), 3.0, dtype=torch.float16, device=dev)
+    wsb = nat.lib().qpal_attn_ws_bytes(nq, nkv, hd, ctx) if split else 0
+    ws = torch.zeros(max(wsb, 4) // 4, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for bad in (ctx, ctx + 5, -1, 1 << 40):
+        pos_t = torch.tensor([bad], dtype=torch.long, device=dev)
+        nat.check(nat.lib().qpal_attn_rope_decode(q32.data_ptr(), k32.data_ptr(), v32.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(),
+                                                  pos_t.data_ptr(), inv_freq.data_ptr(), nq, nkv, hd, ctx, 0.1, ws.data_ptr() if wsb else None,
+                                                  wsb, stream), "qpal_attn_rope_decode")
+        q16 = torch.zeros(nq * hd, dtype=torch.float16, device=dev)
+        nat.check(nat.lib().qpal_rope_kv(q32.data_ptr(), k32.data_ptr(), v32.data_ptr(), q16.data_ptr(), kc.data_ptr(), vc.data_ptr(),
+                                         pos_t.data_ptr(), inv_freq.data_ptr(), nq, nkv, hd, ctx, stream), "qpal_rope_kv")
+        nat.check(nat.lib().qpal_attn_decode(q16.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(), pos_t.data_ptr(), nq, nkv, hd,
+                                             ctx, 0.1, stream), "qpal_attn_decode")
+    torch.cuda.synchronize()
+    assert torch.equal(kc, kc0) and torch.equal(vc, vc0) and float(guard.abs().max()) == 0.0
+    assert bool((out == 3.0).all()) and float(ws.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("qstr", ["tcomb_6_7_0.5_none_0.9", "ldlq_2_8_none_1.0"])
 def test_rmsnorm_fp32_stream_and_accumulate_in_the_gemv_launch(qp, qstr):
     """multi_gemv(..., x = fp32 residual stream, x_rot, x_rms) == rotate(rmsnorm(x).half()) then GEMV; accumulate adds into out."""
