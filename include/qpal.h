@@ -212,6 +212,14 @@ int qpal_tc_to_simt(void *dst_simt, const void *src_tc, int m, int k, int bits, 
 int qpal_hadamard(void *out_f16, const void *in, const void *su, const void *sv, const void *hadk,
                   int rows, int n, int hd, int K, int in_mode, int round_mid, float post_scale, void *stream);
 
+/* RMSNorm + rotation of a whole row in one launch: out = fp16( fp16( H_n (su * w * x / rms(x)) ) * post_scale ), x fp32 [rows][n]
+ * (the residual stream), rms(x) = sqrt(mean(x^2) + rms_eps), w = rms_w (fp16 [n]) or 1 — input_layernorm /
+ * post_attention_layernorm (model/llama.py:119) followed by the left rotation of the incoherent wrappers, for the widths the
+ * GEMV staging cannot rotate itself (qpal_can_fuse_rotation == 0: k = 8192, 5120, ...).  n = K * 2^p as for qpal_hadamard
+ * (hd = n); the norm's scalar is applied after the transform (linear), one fp16 rounding of x * w * 2^-6 on the way in.   */
+int qpal_hadamard_rms(void *out_f16, const float *in_f32, const void *rms_w, float rms_eps, const void *su, const void *hadk,
+                      int rows, int n, int K, float post_scale, void *stream);
+
 /* Host-side encoders of the packed formats (plain CPU code; HOST pointers; no GPU involved): what a quantiser or a
  * checkpoint converter calls once per layer.  Bit for bit the reference's packers:
  *   qpal_pack_tcq         Qidxs int32 [m][k/2] (state t of tile (tr, tc) at [16 tr + t/8][8 tc + t%8]) -> int16

@@ -196,12 +196,27 @@ def main(argv=None):
     attn_ws_bytes = 0 if args.no_split_attention else nat.lib().qpal_attn_ws_bytes(nq, nkv, head_dim, args.context)
     attn_ws = torch.zeros(max(attn_ws_bytes, 4) // 4, dtype=torch.float32, device=dev)
 
+    rot_in_gemv = bool(qp.ops.can_fuse_rotation(1, H))  # k in {2048, 4096}: the GEMV staging rotates x itself
+
+    def _hid(mod, name):
+        """(hadK^T fp16 on the device or None, K) of a module's rotation of the hidden width (cached on the module)"""
+        if not hasattr(mod, name):
+            hk, K = qp.hadamard.get_hadK(H)
+            setattr(mod, name, (None if hk is None else hk.T.contiguous().half().to(dev), K))
+        return getattr(mod, name)
+
     def fused_layer(idx, layer, mask):
         att, mlp = layer.self_attn, layer.mlp
         proj, wsc, blocks = att._qkv_layout()
         widths = [l.out_features for l in proj]
-        qp.multi_gemv(proj, h32, outs=list(qkv32.split(widths, dim=1)), wscales=wsc, oscale=att.scale,
-                      x_rot=(att.SU_qkv, 1.0 / att.scale), x_rms=(eps, layer.input_layernorm.weight))
+        if rot_in_gemv:
+            qp.multi_gemv(proj, h32, outs=list(qkv32.split(widths, dim=1)), wscales=wsc, oscale=att.scale,
+                          x_rot=(att.SU_qkv, 1.0 / att.scale), x_rms=(eps, layer.input_layernorm.weight))
+        else:  # wider hidden sizes (70B: 8192): RMSNorm + rotation as ONE launch of their own, then the plain GEMV launch
+            hk, K = _hid(att, "_hadk_hidden")
+            xr = qp.hadamard.rotate(h32, hadK=hk, K=K, su=att.SU_qkv, post_scale=1.0 / att.scale, in_mode=qp.hadamard.IN_F32,
+                                    rms=(eps, layer.input_layernorm.weight))
+            qp.multi_gemv(proj, xr, outs=list(qkv32.split(widths, dim=1)), wscales=wsc, oscale=att.scale)
         parts = dict(zip([b[0] for b in blocks], qkv32.split([b[1] for b in blocks], dim=1)))
         with torch.cuda.device(dev):
             rc = nat.lib().qpal_attn_rope_decode(parts["q"].data_ptr(), parts["k"].data_ptr(), parts["v"].data_ptr(),
@@ -210,15 +225,27 @@ def main(argv=None):
                                                  attn_ws.data_ptr() if attn_ws_bytes else None, attn_ws_bytes,
                                                  torch.cuda.current_stream(dev).cuda_stream)
         nat.check(rc, "qpal_attn_rope_decode")
-        qp.multi_gemv([att.o_proj], a16, outs=[h32], outs_zeroed=True, wscales=[att.Wscale_o], oscale=att.scale,
-                      x_rot=(att.SU_o, 1.0 / att.scale), accumulate=True)
+        if rot_in_gemv:
+            qp.multi_gemv([att.o_proj], a16, outs=[h32], outs_zeroed=True, wscales=[att.Wscale_o], oscale=att.scale,
+                          x_rot=(att.SU_o, 1.0 / att.scale), accumulate=True)
+        else:
+            hk, K = _hid(att, "_hadk_hidden")
+            xr = qp.hadamard.rotate(a16, hadK=hk, K=K, su=att.SU_o, post_scale=1.0 / att.scale)
+            qp.multi_gemv([att.o_proj], xr, outs=[h32], outs_zeroed=True, wscales=[att.Wscale_o], oscale=att.scale, accumulate=True)
         inter = mlp.intermediate_size
         if mlp.merge_ug:
             ugl, ugw = [mlp.ug_proj], [mlp.Wscale_ug]
         else:
             ugl, ugw = [mlp.up_proj, mlp.gate_proj], [mlp.Wscale_ug[:inter], mlp.Wscale_ug[inter:]]
-        qp.multi_gemv(ugl, h32, outs=list(ug32.split([l.out_features for l in ugl], dim=1)), wscales=ugw, oscale=mlp.scale,
-                      x_rot=(mlp.SU_ug, 1.0 / mlp.scale), x_rms=(eps, layer.post_attention_layernorm.weight))
+        ug_outs = list(ug32.split([l.out_features for l in ugl], dim=1))
+        if rot_in_gemv:
+            qp.multi_gemv(ugl, h32, outs=ug_outs, wscales=ugw, oscale=mlp.scale, x_rot=(mlp.SU_ug, 1.0 / mlp.scale),
+                          x_rms=(eps, layer.post_attention_layernorm.weight))
+        else:
+            hk, K = _hid(mlp, "_hadk_hidden")
+            xr = qp.hadamard.rotate(h32, hadK=hk, K=K, su=mlp.SU_ug, post_scale=1.0 / mlp.scale, in_mode=qp.hadamard.IN_F32,
+                                    rms=(eps, layer.post_attention_layernorm.weight))
+            qp.multi_gemv(ugl, xr, outs=ug_outs, wscales=ugw, oscale=mlp.scale)
         xr = qp.hadamard.rotate(ug32, hadK=mlp.had_left_dp_T, K=mlp.inter_K, su=mlp.SU_dp, post_scale=1.0 / mlp.scale,
                                 in_mode=qp.hadamard.IN_SWIGLU_F32)
         qp.multi_gemv([mlp.down_proj], xr, outs=[h32], outs_zeroed=True, wscales=[mlp.Wscale_dp], oscale=mlp.scale,
@@ -234,10 +261,14 @@ def main(argv=None):
         out_tok.copy_(logits.argmax(-1))
         return hn
 
-    fusable = (not args.no_fused and H in (2048, 4096) and
-               all(qp.linear.rotation_fusable(l.self_attn._qkv_layout()[0], 1) and qp.linear.rotation_fusable([l.self_attn.o_proj], 1)
-                   and isinstance(l.mlp.down_proj, qp.linear._base.PackedLinearBase) and not isinstance(l.mlp.down_proj, qp.VQLinearPackSIMT)
-                   and qp.linear.rotation_fusable([l.mlp.ug_proj] if l.mlp.merge_ug else [l.mlp.up_proj, l.mlp.gate_proj], 1)
+    def _tc(l):
+        return isinstance(l, qp.linear._base.PackedLinearBase) and not isinstance(l, qp.VQLinearPackSIMT)
+
+    fusable = (not args.no_fused and
+               all(all(_tc(p_) for p_ in l.self_attn._qkv_layout()[0]) and _tc(l.self_attn.o_proj) and _tc(l.mlp.down_proj)
+                   and all(_tc(p_) for p_ in ([l.mlp.ug_proj] if l.mlp.merge_ug else [l.mlp.up_proj, l.mlp.gate_proj]))
+                   and (not rot_in_gemv or (qp.linear.rotation_fusable(l.self_attn._qkv_layout()[0], 1)
+                                            and qp.linear.rotation_fusable([l.self_attn.o_proj], 1)))
                    for l in layers))
 
     def timed_fused():

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "qpal_pack_lut_tc": [_P, _P, _I, _I, _I, _I],
     "qpal_pack_lut_simt": [_P, _P, _I, _I, _I, _I],
     "qpal_hadamard": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "qpal_hadamard_rms": [_P, _P, _P, _F, _P, _P, _I, _I, _I, _F, _P],
     "qpal_tcq_chain_build": [_P, ctypes.c_long, ctypes.POINTER(ChainPhase), _I, _I, _I, _I, _I, _I, _I],
     "qpal_lut_chain_build": [_P, ctypes.c_long, ctypes.POINTER(ChainPhase), _I, _I, _I, _I, _I],
     "qpal_chain_launch": [_P, _P, _P, _P, _P],

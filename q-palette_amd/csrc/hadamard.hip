@@ -32,6 +32,10 @@ struct HadParams {
     int npass;             // butterfly passes; pass i handles r[i] index bits in registers (sum r = logP)
     int r[4];
     unsigned long long *dbg;  // HAD_STAMPS diagnostic builds: per-wave s_memtime stamps
+    // RMSNorm in front of the transform (qpal_hadamard_rms; in_mode F32, hd == n): x <- x * rsqrt(mean(x^2) + eps) * w.  The norm's
+    // scalar commutes with the transform: the passes run on x * w * 2^-6 and 64 / rms multiplies the result (had_kernel)
+    float rms_eps;
+    const uint16_t *rms_w;    // fp16 [n] or null
 };
 
 #ifdef HAD_STAMPS
@@ -70,7 +74,7 @@ __device__ __forceinline__ void butterfly(float (&v)[1 << R]) {
 // 2^R consecutive inputs of row `row` starting at column `col` (+ SwiGLU, + sign flip), with the reference's
 // fp16 rounding points.  16-byte vector loads where the run is long enough (alignment checked by the C-ABI).
 template <int R>
-__device__ __forceinline__ void load_input(const HadParams &p, int row, int col, float (&v)[1 << R]) {
+__device__ __forceinline__ void load_input(const HadParams &p, int row, int col, float (&v)[1 << R], float *ss = nullptr) {
     constexpr int E = 1 << R;
     auto load_f32 = [&](const float *src, float (&dst)[E]) {
         if constexpr (E >= 4) {
@@ -101,8 +105,25 @@ __device__ __forceinline__ void load_input(const HadParams &p, int row, int col,
         load_f16(static_cast<const uint16_t *>(p.in) + (long)row * p.n + col, v);
     } else if (p.in_mode == QPAL_IN_F32) {
         load_f32(static_cast<const float *>(p.in) + (long)row * p.n + col, v);
+        if (p.rms_eps > 0.f) {  // RMSNorm: sum of squares of the fp32 input, weight and a power-of-two guard scale, ONE rounding
+            float w[E];
 #pragma unroll
-        for (int j = 0; j < E; j++) v[j] = round_f16(v[j]);
+            for (int j = 0; j < E; j++) w[j] = 1.0f;
+            if (p.rms_w) {
+#pragma unroll
+                for (int j = 0; j < E; j++) w[j] = h2f(p.rms_w[col + j]);
+            }
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                acc += v[j] * v[j];
+                v[j] = round_f16(v[j] * w[j] * 0.015625f);
+            }
+            if (ss) *ss += acc;
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; j++) v[j] = round_f16(v[j]);
+        }
     } else {
         const float *src = static_cast<const float *>(p.in) + (long)row * 2 * p.n + col;
         constexpr int CH = E < 4 ? E : 4;
@@ -144,14 +165,14 @@ __device__ __forceinline__ void load_input(const HadParams &p, int row, int col,
 // FROM_GLOBAL: the first pass (b0 = 0) reads its contiguous run straight from the input; TO_OUT: the last pass of
 // a K = 1 transform scales, rounds and stores fp16 without going back through LDS.
 template <int R, bool FROM_GLOBAL, bool TO_OUT, int NT>
-__device__ __forceinline__ void had_pass(const HadParams &p, float *buf, int b0, int row, int col0, int tid) {
+__device__ __forceinline__ void had_pass(const HadParams &p, float *buf, int b0, int row, int col0, int tid, float *ss = nullptr) {
     constexpr int E = 1 << R;
     const int ngroups = p.hd >> R;
     for (int g = tid; g < ngroups; g += NT) {
         const int i0 = ((g >> b0) << (b0 + R)) | (g & ((1 << b0) - 1));
         float v[E];
         if constexpr (FROM_GLOBAL) {
-            load_input<R>(p, row, col0 + i0, v);
+            load_input<R>(p, row, col0 + i0, v, ss);
         } else {
 #pragma unroll
             for (int j = 0; j < E; j++) v[j] = buf[pad(i0 + (j << b0))];
@@ -174,19 +195,19 @@ __device__ __forceinline__ void had_pass(const HadParams &p, float *buf, int b0,
 }
 
 template <bool FROM_GLOBAL, bool TO_OUT, int NT>
-__device__ __forceinline__ void had_pass_r(int r, const HadParams &p, float *buf, int b0, int row, int col0, int tid) {
+__device__ __forceinline__ void had_pass_r(int r, const HadParams &p, float *buf, int b0, int row, int col0, int tid, float *ss = nullptr) {
     switch (r) {
-        case 1: had_pass<1, FROM_GLOBAL, TO_OUT, NT>(p, buf, b0, row, col0, tid); break;
-        case 2: had_pass<2, FROM_GLOBAL, TO_OUT, NT>(p, buf, b0, row, col0, tid); break;
-        case 3: had_pass<3, FROM_GLOBAL, TO_OUT, NT>(p, buf, b0, row, col0, tid); break;
-        case 4: had_pass<4, FROM_GLOBAL, TO_OUT, NT>(p, buf, b0, row, col0, tid); break;
-        default: had_pass<5, FROM_GLOBAL, TO_OUT, NT>(p, buf, b0, row, col0, tid); break;
+        case 1: had_pass<1, FROM_GLOBAL, TO_OUT, NT>(p, buf, b0, row, col0, tid, ss); break;
+        case 2: had_pass<2, FROM_GLOBAL, TO_OUT, NT>(p, buf, b0, row, col0, tid, ss); break;
+        case 3: had_pass<3, FROM_GLOBAL, TO_OUT, NT>(p, buf, b0, row, col0, tid, ss); break;
+        case 4: had_pass<4, FROM_GLOBAL, TO_OUT, NT>(p, buf, b0, row, col0, tid, ss); break;
+        default: had_pass<5, FROM_GLOBAL, TO_OUT, NT>(p, buf, b0, row, col0, tid, ss); break;
     }
 }
 
 template <int NT>
 __global__ __launch_bounds__(NT) void had_kernel(HadParams p) {
-    extern __shared__ float buf[];  // hd floats, padded (pad())
+    extern __shared__ float buf[];  // hd floats, padded (pad()) [+ NT / 64 partial sums of squares: RMSNorm]
     const int tid = threadIdx.x;
     const int bpr = p.n / p.hd;
     const int row = blockIdx.x / bpr, blk = blockIdx.x - row * bpr;
@@ -218,7 +239,18 @@ __global__ __launch_bounds__(NT) void had_kernel(HadParams p) {
         const bool last = ps == p.npass - 1;
         if (ps == 0) {
             if (last && direct) had_pass_r<true, true, NT>(r, p, buf, 0, row, col0, tid);
-            else had_pass_r<true, false, NT>(r, p, buf, 0, row, col0, tid);
+            else if (p.rms_eps > 0.f) {  // (the host gives an RMSNorm launch at least two passes)
+                float ss = 0.f;
+                had_pass_r<true, false, NT>(r, p, buf, 0, row, col0, tid, &ss);
+#pragma unroll
+                for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+                float *part = buf + p.hd + (p.hd >> 5) + 1;
+                if (lane == 0) part[wave] = ss;
+                __syncthreads();
+                float tot = 0.f;
+                for (int w = 0; w < NT / 64; w++) tot += part[w];
+                p.pre_scale *= __builtin_amdgcn_rsqf(tot / (float)p.hd + p.rms_eps) * 64.0f;  // the later passes scale by it
+            } else had_pass_r<true, false, NT>(r, p, buf, 0, row, col0, tid);
         } else {
             if (last && direct) had_pass_r<false, true, NT>(r, p, buf, b0, row, col0, tid);
             else had_pass_r<false, false, NT>(r, p, buf, b0, row, col0, tid);
@@ -333,6 +365,96 @@ __global__ __launch_bounds__(256) void had_mfma_kernel(HadParams p) {
         [&](int, int, int i, float v) {
             float u = round_f16(v) * p.post_scale;
             if (p.sv) u = round_f16(u) * h2f(p.sv[col0 + i]);
+            orow[i] = f2h(u);
+        });
+}
+
+// K = 1, hd = G * 4096 (8192, 16384, 32768): H_hd = H_G (x) H_4096 and the factors commute — workgroup g of a block first forms
+// y = sum_j (-1)^popc(g & j) x'_j over the G sub-blocks of 4096 (x' = x * su [* w * 2^-6: RMSNorm, scalar applied at the end];
+// it reads the whole block: L2), then runs the 4096-point transform on the matrix pipe (wht64_quad<4>).  y goes in as an
+// fp16 hi + lo pair (staged in LDS by the whole workgroup): sums of a few fp16 values are exact in that form, so the result
+// is fp32-grade like the butterflies'.
+// One workgroup doing all of 8192 on one CU: 12.8 us per launch inside a 70B decode step (had_kernel<768>), 3 per layer.
+template <int G, int MODE, bool RMS>
+__global__ __launch_bounds__(256) void had_split_mfma_kernel(HadParams p) {
+    // y as fp16 hi / lo, formed ONCE per workgroup (every wave of the quad reads all of the transform's input: with the
+    // fp32 + RMSNorm arithmetic inside the tile loader the kernel was instruction-bound, 16.6 us)
+    __shared__ __attribute__((aligned(16))) uint16_t yh[4096], yl[4096];
+    __shared__ float part[4];
+    const int per_row = (p.n / p.hd) * G;
+    const int row = blockIdx.x / per_row, rem = blockIdx.x - row * per_row;
+    const int blk = rem / G, g = rem - blk * G;
+    const int col0 = blk * p.hd;
+    const int tid = threadIdx.x, lane = tid & 63, ct = tid >> 6;
+    uint16_t *orow = p.out + (long)row * p.n + col0 + g * 4096;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int off = 8 * (tid + 256 * c);
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) y[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+            const long at = (long)row * p.n + col0 + j * 4096 + off;
+            float f[8];
+            if constexpr (MODE == QPAL_IN_F16) {
+                const wht_half8 h = *reinterpret_cast<const wht_half8 *>(static_cast<const uint16_t *>(p.in) + at);
+#pragma unroll
+                for (int e = 0; e < 8; e++) f[e] = (float)h[e];
+            } else {
+                const float *src = static_cast<const float *>(p.in) + at;
+                const float4_t a = *reinterpret_cast<const float4_t *>(src), b = *reinterpret_cast<const float4_t *>(src + 4);
+#pragma unroll
+                for (int e = 0; e < 4; e++) f[e] = a[e], f[4 + e] = b[e];
+                if constexpr (RMS) {
+                    wht_half8 w;
+                    if (p.rms_w) w = *reinterpret_cast<const wht_half8 *>(p.rms_w + col0 + j * 4096 + off);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        ss += f[e] * f[e];
+                        f[e] = round_f16(f[e] * (p.rms_w ? (float)w[e] : 1.0f) * 0.015625f);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) f[e] = round_f16(f[e]);  // the reference's .half()
+                }
+            }
+            if (p.su) {
+                const wht_half8 s8 = *reinterpret_cast<const wht_half8 *>(p.su + col0 + j * 4096 + off);
+#pragma unroll
+                for (int e = 0; e < 8; e++) f[e] = round_f16(f[e] * (float)s8[e]);
+            }
+            const bool neg = __builtin_popcount(g & j) & 1;
+#pragma unroll
+            for (int e = 0; e < 8; e++) y[e] += neg ? -f[e] : f[e];
+        }
+        wht_half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            hi[e] = (_Float16)y[e];
+            lo[e] = (_Float16)(y[e] - (float)hi[e]);
+        }
+        *reinterpret_cast<wht_half8 *>(yh + off) = hi;
+        *reinterpret_cast<wht_half8 *>(yl + off) = lo;
+    }
+    float mul = 1.0f;
+    if constexpr (RMS) {
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+        if (lane == 0) part[ct] = ss;
+    }
+    __syncthreads();
+    if constexpr (RMS) mul = __builtin_amdgcn_rsqf((part[0] + part[1] + part[2] + part[3]) / (float)p.hd + p.rms_eps) * 64.0f;
+    wht64_quad<4>(
+        ct, lane, p.pre_scale,
+        [&](int t, int kc) {
+            const int off = (16 * t + (lane & 15)) * 64 + 32 * kc + 8 * (lane >> 4);
+            return wht_hilo{*reinterpret_cast<const wht_half8 *>(yh + off), *reinterpret_cast<const wht_half8 *>(yl + off)};
+        },
+        [&](int, int, int i, float v) {
+            float u = round_f16(v * mul) * p.post_scale;
+            if (p.sv) u = round_f16(u) * h2f(p.sv[col0 + g * 4096 + i]);
             orow[i] = f2h(u);
         });
 }
@@ -462,7 +584,8 @@ void plan_passes(HadParams &p) {
 }
 
 int launch_hadamard(const HadParams &p, hipStream_t stream) {
-    if (p.K > 1 && p.K <= 32 && p.round_mid && p.logP >= 6 && p.logP <= 10 && p.hd > 4096) {
+    const bool rms = p.rms_eps > 0.f;  // the general kernel only (one workgroup per row: it needs the whole row's sum of squares)
+    if (!rms && p.K > 1 && p.K <= 32 && p.round_mid && p.logP >= 6 && p.logP <= 10 && p.hd > 4096) {
         // One launch, K workgroups per block (had_mixfirst_kernel).  History: one workgroup for the whole 14336-vector with
         // SwiGLU 12.4 us; segment transforms + in-place hadK mix as two launches 2 x 4.9 us; a last-arriving workgroup
         // doing the mix behind device-scope fences 18.7 us.
@@ -485,15 +608,28 @@ int launch_hadamard(const HadParams &p, hipStream_t stream) {
 #undef QPAL_MIXFIRST
         return (int)hipGetLastError();
     }
-    if (p.K == 1 && p.in_mode == QPAL_IN_F16 && (p.hd == 1024 || p.hd == 2048 || p.hd == 4096)) {  // 8192: the butterflies win (measured)
+    if (!rms && p.K == 1 && p.in_mode == QPAL_IN_F16 && (p.hd == 1024 || p.hd == 2048 || p.hd == 4096)) {  // 8192: the butterflies win (measured)
         const int g = p.rows * (p.n / p.hd);
         if (p.hd == 1024) hipLaunchKernelGGL((had_mfma_kernel<1>), dim3(g), dim3(256), 0, stream, p);
         else if (p.hd == 2048) hipLaunchKernelGGL((had_mfma_kernel<2>), dim3(g), dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((had_mfma_kernel<4>), dim3(g), dim3(256), 0, stream, p);
         return (int)hipGetLastError();
     }
+    if (p.K == 1 && (p.hd == 8192 || p.hd == 16384 || p.hd == 32768) && p.in_mode != QPAL_IN_SWIGLU_F32 && (!rms || p.hd == p.n)) {
+        const int G = p.hd / 4096;
+        const dim3 grid(p.rows * (p.n / p.hd) * G);
+#define QPAL_HSPLIT(G_)                                                                                              \
+    if (G == G_) {                                                                                                   \
+        if (rms) hipLaunchKernelGGL((had_split_mfma_kernel<G_, QPAL_IN_F32, true>), grid, dim3(256), 0, stream, p);  \
+        else if (p.in_mode == QPAL_IN_F32) hipLaunchKernelGGL((had_split_mfma_kernel<G_, QPAL_IN_F32, false>), grid, dim3(256), 0, stream, p); \
+        else hipLaunchKernelGGL((had_split_mfma_kernel<G_, QPAL_IN_F16, false>), grid, dim3(256), 0, stream, p);     \
+    }
+        QPAL_HSPLIT(2) QPAL_HSPLIT(4) QPAL_HSPLIT(8)
+#undef QPAL_HSPLIT
+        return (int)hipGetLastError();
+    }
     const int grid = p.rows * (p.n / p.hd);
-    const size_t lds = sizeof(float) * (size_t)(p.hd + (p.hd >> 5) + 1);
+    const size_t lds = sizeof(float) * (size_t)(p.hd + (p.hd >> 5) + 1 + 16);
     if (p.hd <= 4096) {  // <= 256 groups of 16: four waves do it
         hipLaunchKernelGGL((had_kernel<256>), dim3(grid), dim3(256), lds, stream, p);
     } else {
@@ -522,8 +658,8 @@ static unsigned long long *g_had_dbg = nullptr;
 extern "C" void qpal_debug_had_stamps(void *buf) { g_had_dbg = static_cast<unsigned long long *>(buf); }
 #endif
 
-extern "C" int qpal_hadamard(void *out_f16, const void *in, const void *su, const void *sv, const void *hadk, int rows,
-                             int n, int hd, int K, int in_mode, int round_mid, float post_scale, void *stream) {
+static int hadamard_impl(void *out_f16, const void *in, const void *su, const void *sv, const void *hadk, int rows, int n, int hd, int K,
+                         int in_mode, int round_mid, float post_scale, float rms_eps, const void *rms_w, void *stream) {
     if (!out_f16 || !in) return QPAL_E_NULL;
     if (out_f16 == in) return QPAL_E_PARAM;  // not in place: the waves of a block read all of it while others already write
     if (K < 1 || K > 256 || (K > 1 && !hadk)) return K > 1 && !hadk ? QPAL_E_NULL : QPAL_E_PARAM;
@@ -533,7 +669,7 @@ extern "C" int qpal_hadamard(void *out_f16, const void *in, const void *su, cons
     const int P = hd / K;
     if (P & (P - 1)) return QPAL_E_SHAPE;
     if (K > 1 && P < 16) return QPAL_E_SHAPE;
-    if (hd < 2 || (hd + (hd >> 5) + 1) * sizeof(float) > 160 * 1024) return QPAL_E_SHAPE;
+    if (hd < 2 || (hd + (hd >> 5) + 1 + 16) * sizeof(float) > 160 * 1024) return QPAL_E_SHAPE;
     int logP = 0;
     while ((1 << logP) < P) logP++;
     const uintptr_t al = reinterpret_cast<uintptr_t>(out_f16) | reinterpret_cast<uintptr_t>(su) |
@@ -544,10 +680,23 @@ extern "C" int qpal_hadamard(void *out_f16, const void *in, const void *su, cons
     if (((size_t)n * (in_mode == QPAL_IN_F16 ? 2 : 4)) % 16 && rows > 1) return QPAL_E_ALIGN;
     HadParams p{static_cast<uint16_t *>(out_f16), in, static_cast<const uint16_t *>(su), static_cast<const uint16_t *>(sv),
                 static_cast<const uint16_t *>(hadk), rows, n, hd, K, logP, in_mode, round_mid ? 1 : 0,
-                (float)(1.0 / sqrt((double)hd)), post_scale, 0, {0, 0, 0, 0}, nullptr};
+                (float)(1.0 / sqrt((double)hd)), post_scale, 0, {0, 0, 0, 0}, nullptr, rms_eps, static_cast<const uint16_t *>(rms_w)};
 #ifdef HAD_STAMPS
     p.dbg = g_had_dbg;
 #endif
     plan_passes(p);
+    if (rms_eps > 0.f && p.npass < 2) return QPAL_E_SHAPE;  // the sum of squares is formed between the first two passes
     return launch_hadamard(p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int qpal_hadamard(void *out_f16, const void *in, const void *su, const void *sv, const void *hadk, int rows,
+                             int n, int hd, int K, int in_mode, int round_mid, float post_scale, void *stream) {
+    return hadamard_impl(out_f16, in, su, sv, hadk, rows, n, hd, K, in_mode, round_mid, post_scale, 0.f, nullptr, stream);
+}
+
+extern "C" int qpal_hadamard_rms(void *out_f16, const float *in_f32, const void *rms_w, float rms_eps, const void *su, const void *hadk,
+                                 int rows, int n, int K, float post_scale, void *stream) {
+    if (!(rms_eps > 0.f)) return QPAL_E_PARAM;
+    if (rms_w && (reinterpret_cast<uintptr_t>(rms_w) & 1)) return QPAL_E_ALIGN;
+    return hadamard_impl(out_f16, in_f32, su, nullptr, hadk, rows, n, n, K, QPAL_IN_F32, 1, post_scale, rms_eps, rms_w, stream);
 }

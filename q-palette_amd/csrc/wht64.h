@@ -19,6 +19,8 @@
 // v_mfma_f32_16x16x32_f16 operand layouts: A lane (q = lane >> 4, r = lane & 15) = A[row r][k = 8q + e];
 // B lane (q, j) = B[k = 8q + e][col j]; D lane (q, j) = D[row 4q + i][col j], i = 0..3.
 #pragma once
+#include <type_traits>
+
 #include "qpal_common.h"
 
 namespace qpal {
@@ -46,8 +48,17 @@ __device__ __forceinline__ u32x4 wht_flip(u32x4 f, uint32_t lo_half, uint32_t hi
 // load_a(t, kc) -> the 8 consecutive inputs x[(16 t + (lane & 15)) * 64 + 32 kc + 8 (lane >> 4) + e] as fp16
 // (pre-multiplied by SU, already rounded);  store(tp, i, elem, v): v = sum * scale (fp32) of element `elem` of the
 // transform, the i-th value (0..3) of this lane in output row tile tp.
-template <int RT, int TCH_MAX = 4, class LoadA, class Store>
-__device__ __forceinline__ void wht64_quad(int ct, int lane, float scale, LoadA &&load_a, Store &&store) {
+// A-operand input as an fp16 hi + lo pair (fp32-grade inputs: two MFMAs per tile in stage 1)
+struct wht_hilo {
+    wht_half8 hi, lo;
+};
+
+// (after_stage1: called once when every input has been loaded — the place to finish a reduction over the inputs that the
+// store needs, e.g. an RMSNorm's sum of squares)
+template <int RT, int TCH_MAX = 4, class LoadA, class Store, class After = void (*)()>
+__device__ __forceinline__ void wht64_quad(int ct, int lane, float scale, LoadA &&load_a, Store &&store, After &&after_stage1 = [] {}) {
+    using AT = decltype(load_a(0, 0));
+    constexpr bool HILO = std::is_same_v<AT, wht_hilo>;
     const uint32_t q = lane >> 4, j = lane & 15;
     constexpr uint32_t M = 0x80008000u;
 
@@ -65,7 +76,7 @@ __device__ __forceinline__ void wht64_quad(int ct, int lane, float scale, LoadA 
     constexpr int TCH = RT < TCH_MAX ? RT : TCH_MAX;  // row tiles whose loads are in flight together
 #pragma unroll
     for (int t0 = 0; t0 < RT; t0 += TCH) {
-        wht_half8 a[TCH][2];
+        AT a[TCH][2];
 #pragma unroll
         for (int t = 0; t < TCH; t++) {
             a[t][0] = load_a(t0 + t, 0);
@@ -74,11 +85,19 @@ __device__ __forceinline__ void wht64_quad(int ct, int lane, float scale, LoadA 
 #pragma unroll
         for (int t = 0; t < TCH; t++) {
             wht_float4 acc{0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][0], __builtin_bit_cast(wht_half8, b1[0]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][1], __builtin_bit_cast(wht_half8, b1[1]), acc, 0, 0, 0);
+            if constexpr (HILO) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][0].hi, __builtin_bit_cast(wht_half8, b1[0]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][0].lo, __builtin_bit_cast(wht_half8, b1[0]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][1].hi, __builtin_bit_cast(wht_half8, b1[1]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][1].lo, __builtin_bit_cast(wht_half8, b1[1]), acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][0], __builtin_bit_cast(wht_half8, b1[0]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][1], __builtin_bit_cast(wht_half8, b1[1]), acc, 0, 0, 0);
+            }
             d1[t0 + t] = acc;
         }
     }
+    after_stage1();
 
     // ---- stage 2 operands.  B: tiles (2 kc, 2 kc + 1) of this lane, scaled by 1/8 (exact; keeps fp16 in range), as
     // hi + lo.  A[row rho' = 16 t' + r][slot (q, e)] = (-1)^popc(rho' & rho), rho = 32 kc + 16 (e >> 2) + 4 q + (e & 3):

@@ -109,9 +109,11 @@ def get_hadK(n, transpose=False):
     return None, 1
 
 
-def rotate(x, hd=None, hadK=None, K=1, su=None, sv=None, post_scale=1.0, in_mode=IN_F16, round_mid=True, out=None):
+def rotate(x, hd=None, hadK=None, K=1, su=None, sv=None, post_scale=1.0, in_mode=IN_F16, round_mid=True, out=None, rms=None):
     """One launch of ``qpal_hadamard`` (see include/qpal.h).  x: [..., n] fp16 | fp32, or [..., 2n] fp32 for
-    in_mode = IN_SWIGLU_F32 (up | gate).  Returns fp16 [..., n]."""
+    in_mode = IN_SWIGLU_F32 (up | gate).  Returns fp16 [..., n].
+    rms = (eps, weight fp16 [n] or None): RMSNorm of the fp32 row in front of the rotation, same launch (``qpal_hadamard_rms``;
+    in_mode IN_F32, hd = n, no sv) — the decoder-block fusion for widths the GEMV staging cannot rotate itself."""
     if not x.is_cuda:
         raise _native.QpalError("qpalette_amd has no CPU implementation: rotate() needs device tensors")
     want = torch.float16 if in_mode == IN_F16 else torch.float32
@@ -142,6 +144,15 @@ def rotate(x, hd=None, hadK=None, K=1, su=None, sv=None, post_scale=1.0, in_mode
         raise _native.QpalError("rotate: x and out must live on the same GPU")
     # launch on x's device and ITS current stream (a module on cuda:N of a device_map'ed model is called while another
     # device is current: the GEMVs around the rotation already run on cuda:N's stream, ops.py)
+    if rms is not None:
+        eps, w = rms
+        if in_mode != IN_F32 or hd != n or sv is not None or not round_mid:
+            raise _native.QpalError("rotate: rms needs in_mode IN_F32, hd = n, no sv")
+        with torch.cuda.device_of(x):
+            _native.check(_native.lib().qpal_hadamard_rms(out.data_ptr(), x.data_ptr(), vec(w, "rms weight"), float(eps), vec(su, "su"),
+                                                          hk, rows, n, K, float(post_scale),
+                                                          torch.cuda.current_stream(x.device).cuda_stream), "qpal_hadamard_rms")
+        return out
     with torch.cuda.device_of(x):
         _native.check(_native.lib().qpal_hadamard(out.data_ptr(), x.data_ptr(), vec(su, "su"), vec(sv, "sv"), hk, rows, n, hd,
                                                   K, in_mode, 1 if round_mid else 0, float(post_scale),

@@ -182,12 +182,35 @@ def test_rmsnorm_fp32_stream_and_accumulate_in_the_gemv_launch(qp, qstr):
     assert torch.allclose(acc, got + 0.5, atol=tol, rtol=2e-3)
 
 
-def test_fused_decode_step_matches_modular_step(qp):
-    """perf/decode_llama.py: the fused-glue step (8 launches per layer) and the modular Incoherent* step (torch glue) produce the
-    same normalised hidden state for the same random 2-layer Llama-3.1-8B-shaped model."""
+@pytest.mark.parametrize("n", [8192, 5120, 4096, 2048, 11008])
+def test_rmsnorm_inside_the_rotation_launch(qp, n):
+    """rotate(x fp32, rms=(eps, w)) == rotate(rmsnorm(x).half()): the widths whose rotation cannot run inside the GEMV staging
+    (8192 = Llama-70B hidden, 5120 = 13B: K = 20, 11008 = 172 * 64) and, for comparison, the ones that can."""
+    dev = torch.device("cuda", 0)
+    had = qp.hadamard
+    gen = torch.Generator(device=dev).manual_seed(n)
+    x = torch.randn(3, n, device=dev, generator=gen) * torch.tensor([[0.02], [3.0], [400.0]], device=dev)  # residual-stream magnitudes
+    w = (1.0 + 0.1 * torch.randn(n, device=dev, generator=gen)).half()
+    su = (torch.randint(0, 2, (n,), device=dev, generator=gen) * 2 - 1).half()
+    hadK, K = had.get_hadK(n)
+    hk = None if K == 1 else hadK.T.contiguous().half().to(dev)
+    eps = 1e-5
+    xn = torch.nn.functional.rms_norm(x, (n,), w.float(), eps).half()
+    ref = had.rotate(xn, hadK=hk, K=K, su=su, post_scale=1 / 32).float()
+    got = had.rotate(x, hadK=hk, K=K, su=su, post_scale=1 / 32, in_mode=had.IN_F32, rms=(eps, w)).float()
+    torch.cuda.synchronize()
+    tol = 2.0 ** -9 * float(ref.abs().max())  # the norm's scalar is applied after the transform: inputs round at another point
+    assert torch.allclose(got, ref, atol=tol, rtol=4e-3), float((got - ref).abs().max())
+
+
+@pytest.mark.parametrize("model", ["3_8b", "3_70b"])
+def test_fused_decode_step_matches_modular_step(qp, model):
+    """perf/decode_llama.py: the fused-glue step (6 launches per layer; 9 where the hidden width's rotation cannot run inside the
+    GEMV staging: 70B's 8192 takes RMSNorm + rotation as one launch of its own) and the modular Incoherent* step (torch glue)
+    produce the same normalised hidden state for the same random 2-layer model."""
     sys.path.insert(0, os.path.join(ROOT, "perf"))
     import decode_llama
-    res = decode_llama.main(["--layers", "2", "--tokens", "4", "--context", "128", "--vocab", "4096"])
+    res = decode_llama.main(["--model", model, "--layers", "2", "--tokens", "4", "--context", "128", "--vocab", "4096"])
     chk = res["check"]
     assert chk is not None and res["ms_fused_glue"] is not None
     assert chk["max_abs_diff_final_norm"] <= 2.0 ** -7 * max(1.0, chk["max_abs_ref"]), chk
