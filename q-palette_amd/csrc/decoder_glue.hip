@@ -292,7 +292,7 @@ __global__ __launch_bounds__(1024) void attn_rope_decode_kernel(const AttnRopePa
 // per group instead of once per head), leaves a partial (max, sum, unnormalised out) per head in a workspace and takes a
 // ticket; the last workgroup of a kv head to arrive merges the partials (agent-scope stores and loads: the L2s of the 8 XCDs
 // are not coherent with each other) and resets the ticket for the next launch.
-constexpr long kAttnPlainBelow = 768;  // positions below which the split-context launch runs the one-workgroup-per-head body
+constexpr long kAttnPlainBelow = 512;  // positions below which the split-context launch runs the one-workgroup-per-head body
 
 struct AttnSplitParams {
     AttnRopeParams a;
@@ -313,21 +313,21 @@ __global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSpli
     constexpr int LPR = HD / 8, DPL = HD / 64;
     static_assert(REP * HD <= 1024, "partial-out buffer: NW x REP x HD floats of LDS");
     const AttnRopeParams &p = sp.a;
-    extern __shared__ float sh[];  // scores [REP][chunk] | q [REP][HD/2 dwords] | new k [HD/2 dwords] | new v [HD] | partial out [NW][REP][HD] | reduce [2 NW REP] | new-position scores [REP] | flag
+    extern __shared__ float sh[];  // scores [REP][chunk] | q [REP][HD/2 dwords] | new k [HD/2 dwords] | new v [HD] | partial out [NW][REP][HD] | reduce [2 NW REP] | new-position scores, maxima, sums [3 REP] | flag
     const int CL = sp.chunk;
     float *sc = sh;
     uint32_t *qh = reinterpret_cast<uint32_t *>(sh + REP * CL), *knh = qh + REP * HALF;
     float *vn = reinterpret_cast<float *>(knh + HALF), *po = vn + HD, *red = po + NW * REP * HD;
-    float *park = red + 2 * NW * REP;
-    unsigned *flag = reinterpret_cast<unsigned *>(park + REP);
+    float *park = red + 2 * NW * REP, *mxf = park + REP, *sumf = mxf + REP;
+    unsigned *flag = reinterpret_cast<unsigned *>(sumf + REP);
     const int kh = blockIdx.x / sp.nsplit, split = blockIdx.x - kh * sp.nsplit;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long pos = *p.pos;
     if (pos < 0 || pos >= p.max_len) return;  // position outside the cache: nothing is read or written, no ticket taken
     // A short context in a long cache: the first nq workgroups run the one-head body, the others leave.  Measured per launch
     // (32 heads, 8 kv heads, hd 128): one-head body 4.9 us at 40 positions, 9.8 at 500, 28.5 at 2000, 62 at 4000, 457 at 32 k;
-    // this kernel's group form 12.6 at 500, 16.5 at 2000, 18.4 at 4000, 38 at 32 k (134 MB: 3.5 TB/s) — its floor is the
-    // partial / ticket / merge round trips at agent scope.
+    // this kernel's group form 10.0 at 800, 13.5 at 2000, 15.4 at 4000, 18.2 at 8000, 35 at 32 k (134 MB: 3.8 TB/s; 8 heads per
+    // group: 20 at 8000) — its floor is the partial / ticket / merge round trips at agent scope.
     if (pos < kAttnPlainBelow) {
         if ((int)blockIdx.x < p.nq) attn_rope_head<HD, NW>(p, sh, blockIdx.x, pos, kAttnPlainBelow);
         return;
@@ -379,49 +379,52 @@ __global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSpli
 
         // ---- scores
         const int grp = lane / LPR, sl = lane % LPR;
-        float mx[REP];
-#pragma unroll
-        for (int h = 0; h < REP; h++) mx[h] = -3.0e38f;
         // Scores on the matrix pipe: D[head][position] = Q[head][:] . K[position][:], v_mfma_f32_16x16x32_f16 with the group's
         // query heads as the (zero-padded) 16 rows of A and 16 cache rows as B.  A B fragment is lane (column j = position,
         // q = lane >> 4): 8 consecutive dims 32 kc + 8 q .. of row j = one 16-byte load; the wave's HD/32 loads cover 16 whole
         // rows.  No cross-lane reduction, no VALU beside the scale: the dot-product form (v_dot2 + a 4-step xor reduction per
         // head and row group) made a chunk VALU-bound — 500 positions for 4 heads: 19.7 us on one CU.
-        constexpr int U = REP > 4 ? 1 : 2;  // 16-row tiles in flight per wave (registers: 8 heads keep 8 maxima, sums and accumulators live)
+        // Per-head bookkeeping (maxima, sums, the new position's weight) lives in LDS, not in per-thread arrays of REP values:
+        // a lane keeps only the four heads its accumulator rows hold (8 heads per group used to spill and ran 2.5x slower).
+        constexpr int U = 2;    // 16-row tiles in flight per wave
         constexpr int KC = HD / 32;
         typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
         typedef float float4_t __attribute__((ext_vector_type(4)));
         const int mi = lane & 15, mq = lane >> 4;
-        half8_t afr[KC];
+        float mx4[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};  // heads 4 mq + r
+        {
+            half8_t afr[KC];
 #pragma unroll
-        for (int kc = 0; kc < KC; kc++) {
-            u32x4 a{0u, 0u, 0u, 0u};
-            if (mi < REP) a = *reinterpret_cast<const u32x4 *>(qh + mi * HALF + 16 * kc + 4 * mq);
-            afr[kc] = __builtin_bit_cast(half8_t, a);
-        }
-        for (int t0 = wave * 16; t0 < nc; t0 += NW * 16 * U) {
-            u32x4 kb[U][KC];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int t = t0 + u * NW * 16 + mi;
-                const gptr<const uint16_t> row = K + (c0 + (t < nc ? t : 0)) * HD + 8 * mq;
-#pragma unroll
-                for (int kc = 0; kc < KC; kc++) kb[u][kc] = *(gptr<const u32x4>)(row + 32 * kc);
+            for (int kc = 0; kc < KC; kc++) {
+                u32x4 a{0u, 0u, 0u, 0u};
+                if (mi < REP) a = *reinterpret_cast<const u32x4 *>(qh + mi * HALF + 16 * kc + 4 * mq);
+                afr[kc] = __builtin_bit_cast(half8_t, a);
             }
+            for (int t0 = wave * 16; t0 < nc; t0 += NW * 16 * U) {
+                u32x4 kb[U][KC];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int t = t0 + u * NW * 16 + mi;
-                float4_t d{0.f, 0.f, 0.f, 0.f};
+                for (int u = 0; u < U; u++) {
+                    const int t = t0 + u * NW * 16 + mi;
+                    const gptr<const uint16_t> row = K + (c0 + (t < nc ? t : 0)) * HD + 8 * mq;
 #pragma unroll
-                for (int kc = 0; kc < KC; kc++)
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[kc], __builtin_bit_cast(half8_t, kb[u][kc]), d, 0, 0, 0);
-                // lane (mq, mi): rows 4 mq + r (heads), column mi (position t)
+                    for (int kc = 0; kc < KC; kc++) kb[u][kc] = *(gptr<const u32x4>)(row + 32 * kc);
+                }
 #pragma unroll
-                for (int h = 0; h < REP; h++) {
-                    if ((h >> 2) == mq && t < nc) {
-                        const float a = d[h & 3] * p.scale;
-                        sc[h * CL + t] = a;
-                        mx[h] = a > mx[h] ? a : mx[h];
+                for (int u = 0; u < U; u++) {
+                    const int t = t0 + u * NW * 16 + mi;
+                    float4_t d{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++)
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[kc], __builtin_bit_cast(half8_t, kb[u][kc]), d, 0, 0, 0);
+                    if (4 * mq < REP && t < nc) {  // lane (mq, mi): rows 4 mq + r (heads), column mi (position t)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            if (4 * mq + r < REP) {
+                                const float a = d[r] * p.scale;
+                                sc[(4 * mq + r) * CL + t] = a;
+                                mx4[r] = a > mx4[r] ? a : mx4[r];
+                            }
+                        }
                     }
                 }
             }
@@ -431,58 +434,55 @@ __global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSpli
             if (grp == 0) kn = *reinterpret_cast<const u32x4 *>(knh + 4 * sl);
 #pragma unroll
             for (int h = 0; h < REP; h++) {
-                const u32x4 qv = *reinterpret_cast<const u32x4 *>(qh + h * HALF + 4 * sl);  // loaded here: not live across the tile loop
+                const u32x4 qv = *reinterpret_cast<const u32x4 *>(qh + h * HALF + 4 * sl);
                 float a = fdot2(kn.x, qv.x, 0.f);
                 a = fdot2(kn.y, qv.y, a);
                 a = fdot2(kn.z, qv.z, a);
                 a = fdot2(kn.w, qv.w, a);
 #pragma unroll
                 for (int sft = 1; sft < LPR; sft <<= 1) a += __shfl_xor(a, sft, 64);
-                a *= p.scale;
-                if (lane == 0) park[h] = a;
-                if (grp == 0) mx[h] = a > mx[h] ? a : mx[h];
+                if (lane == 0) park[h] = a * p.scale;
             }
         }
 #pragma unroll
-        for (int h = 0; h < REP; h++) {
-            float m = mx[h];
+        for (int r = 0; r < 4; r++) {  // maximum over the 16 positions (lanes) of this lane's head group, per wave
+            float m = mx4[r];
 #pragma unroll
-            for (int sft = 32; sft >= 1; sft >>= 1) { const float o = __shfl_xor(m, sft, 64); m = o > m ? o : m; }
-            if (lane == 0) red[h * NW + wave] = m;
+            for (int sft = 8; sft >= 1; sft >>= 1) { const float o = __shfl_xor(m, sft, 64); m = o > m ? o : m; }
+            if (mi == 0 && 4 * mq + r < REP) red[(4 * mq + r) * NW + wave] = m;
         }
         __syncthreads();
-        float snew[REP];
+        if (tid < REP) {
+            float m = red[tid * NW];
 #pragma unroll
-        for (int h = 0; h < REP; h++) {
-            float m = red[h * NW];
-#pragma unroll
-            for (int w = 1; w < NW; w++) m = red[h * NW + w] > m ? red[h * NW + w] : m;
-            mx[h] = m;
-            snew[h] = owner ? park[h] : 0.f;
-            if constexpr (REP > 4) __builtin_amdgcn_sched_barrier(0);  // one head at a time: 8 x 16 hoisted LDS reads spill
+            for (int w = 1; w < NW; w++) m = red[tid * NW + w] > m ? red[tid * NW + w] : m;
+            if (owner) m = park[tid] > m ? park[tid] : m;
+            mxf[tid] = m;
         }
-        float sum[REP];
-#pragma unroll
-        for (int h = 0; h < REP; h++) {
-            float s = 0.f;
-            for (int t = tid; t < nc; t += NT) {
-                const float e = __expf(sc[h * CL + t] - mx[h]);
-                sc[h * CL + t] = e;
-                s += e;
+        __syncthreads();
+        {   // exponentials and their sums: wave -> (head wave % REP, part wave / REP of the chunk)
+            constexpr int NP = NW / REP;
+            const int hh = wave % REP, pw = wave / REP;
+            const float m = mxf[hh];
+            float sm = 0.f;
+            for (int t = pw * 64 + lane; t < nc; t += 64 * NP) {
+                const float e = __expf(sc[hh * CL + t] - m);
+                sc[hh * CL + t] = e;
+                sm += e;
             }
 #pragma unroll
-            for (int sft = 32; sft >= 1; sft >>= 1) s += __shfl_xor(s, sft, 64);
-            if (lane == 0) red[NW * REP + h * NW + wave] = s;
-            snew[h] = owner ? __expf(snew[h] - mx[h]) : 0.f;
+            for (int sft = 32; sft >= 1; sft >>= 1) sm += __shfl_xor(sm, sft, 64);
+            if (lane == 0) red[NW * REP + wave] = sm;
         }
         __syncthreads();
+        if (tid < REP) {
+            constexpr int NP = NW / REP;
+            float sm = 0.f;
 #pragma unroll
-        for (int h = 0; h < REP; h++) {
-            float s = snew[h];
-#pragma unroll
-            for (int w = 0; w < NW; w++) s += red[NW * REP + h * NW + w];
-            sum[h] = s;
-            if constexpr (REP > 4) __builtin_amdgcn_sched_barrier(0);
+            for (int pw = 0; pw < NP; pw++) sm += red[NW * REP + pw * REP + tid];
+            const float wn = owner ? __expf(park[tid] - mxf[tid]) : 0.f;
+            park[tid] = wn;  // from here on: the new position's softmax weight
+            sumf[tid] = sm + wn;
         }
 
         // ---- values
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSpli
         for (int h = 0; h < REP; h++)
 #pragma unroll
             for (int e = 0; e < DPL; e++) acc[h][e] = 0.f;
-        constexpr int UV = REP * DPL > 8 ? 2 : 4;  // rows in flight per wave in the value loop (latency-bound: one wave = a serial chain of loads)
+        constexpr int UV = REP * DPL > 16 ? 2 : 4;  // rows in flight per wave in the value loop (latency-bound: one wave = a serial chain of loads)
         for (int t0 = wave; t0 < nc; t0 += NW * UV) {
             uint16_t raw[UV][DPL];
 #pragma unroll
@@ -513,44 +513,24 @@ __global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSpli
                 }
             }
         }
-        if (owner && wave == 0) {
-#pragma unroll
-            for (int h = 0; h < REP; h++)
-#pragma unroll
-                for (int e = 0; e < DPL; e++) acc[h][e] += snew[h] * vn[DPL * lane + e];
-        }
 #pragma unroll
         for (int h = 0; h < REP; h++)
 #pragma unroll
             for (int e = 0; e < DPL; e++) po[(wave * REP + h) * HD + DPL * lane + e] = acc[h][e];
-        __syncthreads();
-        if (neff == 1) {  // the only chunk: no partials, no ticket
-#pragma unroll
-            for (int h = 0; h < REP; h++)
-                if (tid == h) park[h] = sum[h];
-            __syncthreads();
-            for (int idx = tid; idx < REP * HD; idx += NT) {
-                float v = 0.f;
-#pragma unroll
-                for (int w = 0; w < NW; w++) v += po[w * REP * HD + idx];
-                const int h = idx / HD;
-                p.out[(long)(kh * REP) * HD + idx] = __builtin_bit_cast(uint16_t, (_Float16)(v / park[h]));
-            }
-            return;
-        }
+        __syncthreads();  // (also orders park / sumf, written by the first REP threads above, before the reads below)
         for (int idx = tid; idx < REP * HD; idx += NT) {
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; w++) v += po[w * REP * HD + idx];
             const int h = idx / HD, d = idx - h * HD;
-            st_agent_f(wsp + h * (HD + 2) + 2 + d, v);
+            if (owner) v += park[h] * vn[d];
+            if (neff == 1) p.out[(long)(kh * REP) * HD + idx] = __builtin_bit_cast(uint16_t, (_Float16)(v / sumf[h]));  // the only chunk
+            else st_agent_f(wsp + h * (HD + 2) + 2 + d, v);
         }
-#pragma unroll
-        for (int h = 0; h < REP; h++) {
-            if (tid == h) {
-                st_agent_f(wsp + h * (HD + 2), mx[h]);
-                st_agent_f(wsp + h * (HD + 2) + 1, sum[h]);
-            }
+        if (neff == 1) return;  // no partials, no ticket
+        if (tid < REP) {
+            st_agent_f(wsp + tid * (HD + 2), mxf[tid]);
+            st_agent_f(wsp + tid * (HD + 2) + 1, sumf[tid]);
         }
     }
     // ---- ticket: the stores above are write-through; wait for them, then arrive
@@ -653,7 +633,7 @@ static void attn_split_geometry(int nq, int nkv, int hd, long max_len, int &nspl
     // 16 waves whatever the chunk: with 4 (tried for short chunks) every wave walks 4x the rows, one load latency at a time
     // (8192-position cache at 500 positions: 30 us against 10)
     const int nw = 16;
-    const size_t floats = (size_t)rep * c + (size_t)rep * hd / 2 + hd / 2 + hd + nw * (size_t)rep * hd + 2 * nw * (size_t)rep + rep + 4;
+    const size_t floats = (size_t)rep * c + (size_t)rep * hd / 2 + hd / 2 + hd + nw * (size_t)rep * hd + 2 * nw * (size_t)rep + 3 * rep + 4;
     const size_t plain = (size_t)kAttnPlainBelow + 2 * hd + nw * (size_t)hd + 2 * nw;  // attn_rope_head's layout at cap = kAttnPlainBelow
     const size_t need = floats > plain ? floats : plain;
     if (ns < 2 || nkv * ns < nq || need * sizeof(float) > 160 * 1024) return;

@@ -75,8 +75,8 @@ def test_rope_kv_and_attn_decode_match_torch(qp, nq, nkv, hd, ctx, pos):
     (32, 8, 128, 2048, 0, True), (32, 8, 128, 2048, 63, True), (32, 8, 128, 2048, 64, True), (32, 8, 128, 2048, 1300, True),
     (32, 8, 128, 4096, 4095, True), (64, 8, 128, 8192, 5000, True), (8, 8, 64, 4096, 2049, True), (16, 4, 256, 2048, 2047, True),
     (32, 8, 128, 32768, 31000, True), (32, 8, 128, 512, 100, True),
-    # below 768 positions the split launch runs the one-head body; above, the existing context is cut evenly over the splits
-    (32, 8, 128, 2048, 767, True), (32, 8, 128, 2048, 768, True), (32, 8, 128, 32768, 800, True), (64, 8, 128, 32768, 1023, True),
+    # below 512 positions the split launch runs the one-head body; above, the existing context is cut evenly over the splits
+    (32, 8, 128, 2048, 511, True), (32, 8, 128, 2048, 512, True), (32, 8, 128, 2048, 768, True), (8, 1, 128, 8192, 5000, True), (32, 8, 128, 32768, 800, True), (64, 8, 128, 32768, 1023, True),
     (32, 8, 128, 32768, 2047, True), (32, 8, 128, 32768, 2048, True)])
 def test_attn_rope_decode_one_launch_matches_torch(qp, nq, nkv, hd, ctx, pos, split):
     """qpal_attn_rope_decode = rope + cache append + attention in one launch: equals the two-launch pair's math (torch
