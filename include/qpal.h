@@ -259,6 +259,15 @@ int qpal_rope_kv(const float *q, const float *k, const float *v, void *q_out_f16
 int qpal_attn_decode(const void *q_f16, const void *kcache_f16, const void *vcache_f16, void *out_f16, const long *pos,
                      int nq, int nkv, int hd, long max_len, float scale, void *stream);
 
+/* The tail of a greedy decode step as one launch: x = fp16(rmsnorm(h) [* rms_w]) (rms_eps = 0: x = fp16(h)), logits = W x with
+ * W the fp16 lm_head [vocab][k] (k in {2048, 4096, 8192}, 16-byte aligned), *token = argmax (lowest index on ties); logits
+ * (fp32 [vocab]) are also written when the pointer is not NULL.  ws: qpal_lm_head_ws_bytes(vocab) bytes of device memory,
+ * zero-filled once, kept across launches.  Replaces model.norm + lm_head + argmax of the reference's decode loop
+ * (eval/measure_latency.py: logits[:, -1].argmax).                                                                          */
+long qpal_lm_head_ws_bytes(int vocab);
+int qpal_lm_head_argmax(const float *h_f32, const void *rms_w_f16, float rms_eps, const void *w_f16, float *logits_f32, long *token,
+                        void *ws, long ws_bytes, int vocab, int k, void *stream);
+
 /* The two launches above as one (what a decode step runs): rotary embedding of the new token's q / k, k and v appended to the
  * cache at *pos, attention over positions 0 .. *pos, fp16 out [nq][hd].  q / k / v fp32 as for qpal_rope_kv.  hd in {64, 128,
  * 256}; max_len % 4 == 0.  The new row is read from on-chip memory by every head of its group: nothing this launch reads was

@@ -106,6 +106,7 @@ def main(argv=None):
     ap.add_argument("--start-pos", type=int, default=8, help="position of the first timed token (the cache below it is attended over)")
     ap.add_argument("--vocab", type=int, default=128256)
     ap.add_argument("--no-fused", action="store_true", help="skip the fused-glue step (third figure)")
+    ap.add_argument("--torch-lm-head", action="store_true", help="fused step: final norm, lm_head and argmax as torch ops (hipBLASLt GEMV)")
     ap.add_argument("--no-split-attention", action="store_true", help="one workgroup per query head at every context length")
     ap.add_argument("--no-modular", action="store_true", help="time the fused-glue step only (profiling)")
     args = ap.parse_args(argv)
@@ -195,6 +196,9 @@ def main(argv=None):
     # long caches: split-context attention (one workspace serves every layer: launches are stream-ordered)
     attn_ws_bytes = 0 if args.no_split_attention else nat.lib().qpal_attn_ws_bytes(nq, nkv, head_dim, args.context)
     attn_ws = torch.zeros(max(attn_ws_bytes, 4) // 4, dtype=torch.float32, device=dev)
+    lm_ws_bytes = nat.lib().qpal_lm_head_ws_bytes(args.vocab)
+    lm_ws = torch.zeros(lm_ws_bytes // 4, dtype=torch.float32, device=dev)
+    want_hidden = [False]  # the parity check below wants the normalised hidden state back (an extra torch norm, not timed)
 
     rot_in_gemv = bool(qp.ops.can_fuse_rotation(1, H))  # k in {2048, 4096}: the GEMV staging rotates x itself
 
@@ -256,10 +260,17 @@ def main(argv=None):
         mask = torch.where(ar <= pos, 0.0, float("-inf")).half().view(1, 1, 1, -1)
         for idx, layer in enumerate(layers):
             fused_layer(idx, layer, mask)
-        hn = norm(h32.half().view(1, 1, H))
-        logits = hn.view(1, H) @ lm_head.T
-        out_tok.copy_(logits.argmax(-1))
-        return hn
+        if args.torch_lm_head:
+            hn = norm(h32.half().view(1, 1, H))
+            logits = hn.view(1, H) @ lm_head.T
+            out_tok.copy_(logits.argmax(-1))
+            return hn
+        with torch.cuda.device(dev):  # final RMSNorm + lm_head GEMV + argmax: one launch
+            rc = nat.lib().qpal_lm_head_argmax(h32.data_ptr(), norm.weight.data_ptr(), norm.eps, lm_head.data_ptr(), None,
+                                               out_tok.data_ptr(), lm_ws.data_ptr(), lm_ws_bytes, args.vocab, H,
+                                               torch.cuda.current_stream(dev).cuda_stream)
+        nat.check(rc, "qpal_lm_head_argmax")
+        return norm(h32.half().view(1, 1, H)) if want_hidden[0] else None
 
     def _tc(l):
         return isinstance(l, qp.linear._base.PackedLinearBase) and not isinstance(l, qp.VQLinearPackSIMT)
@@ -298,7 +309,9 @@ def main(argv=None):
         ref_h = norm(step(True).view(1, 1, H)).float()
         tok.zero_()
         pos.fill_(3)
+        want_hidden[0] = True
         got_h = fused_step().float()
+        want_hidden[0] = False
         check = {"max_abs_diff_final_norm": float((ref_h - got_h).abs().max()), "max_abs_ref": float(ref_h.abs().max())}
     if args.no_modular:
         if not fusable:

@@ -68,6 +68,8 @@ _SIGNATURES = {
     "qpal_attn_decode": [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_long, _F, _P],
     "qpal_attn_rope_decode": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_long, _F, _P, ctypes.c_long, _P],
     "qpal_attn_ws_bytes": [_I, _I, _I, ctypes.c_long],
+    "qpal_lm_head_argmax": [_P, _P, _F, _P, _P, _P, _P, ctypes.c_long, _I, _I, _P],
+    "qpal_lm_head_ws_bytes": [_I],
     "qpal_peer_gather": [_P, ctypes.c_long, _I, ctypes.POINTER(_P), ctypes.POINTER(_P), _I, _I, _P],
 }
 
@@ -101,6 +103,7 @@ def lib():
         l.qpal_chain_blob_bytes.argtypes = [_I]
         l.qpal_chain_blob_bytes.restype = ctypes.c_long
         l.qpal_attn_ws_bytes.restype = ctypes.c_long
+        l.qpal_lm_head_ws_bytes.restype = ctypes.c_long
         _lib = l
     return _lib
 

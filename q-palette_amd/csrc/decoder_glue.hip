@@ -583,6 +583,138 @@ __global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSpli
     if (tid == 0) __hip_atomic_store(as_global(ticket), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// qpal_lm_head_argmax: the last launches of a greedy decode step as one — final RMSNorm of the fp32 residual stream, the fp16
+// lm_head GEMV (vocab x k, the one unquantized matrix of the model: 1.05 GB for Llama-3.1-8B), optional logits, and the argmax.
+// A wave owns rows r = gw, gw + nw, ...: 64 lanes x 16 bytes per load, the normalised x held in registers as packed fp16
+// (v_dot2), two rows in flight; per-workgroup (max, index) partials go out with agent-scope stores and the last workgroup to
+// take a ticket reduces them (ties: the lowest index, like torch.argmax).  As torch ops the same work is a norm (3 launches),
+// a hipBLASLt GEMV (186 us), and a 47 us reduction over 128 k logits.
+struct LmHeadParams {
+    const float *h;          // fp32 [k] residual stream
+    const uint16_t *rms_w;   // fp16 [k] or null
+    float rms_eps;           // 0: no norm (x = fp16(h))
+    const uint16_t *w;       // fp16 [vocab][k]
+    float *logits;           // fp32 [vocab] or null
+    long *token;             // argmax
+    float *ws;               // [2 * grid] partial (max, index as float bits) + ticket (zero-filled once)
+    int vocab, k;
+};
+
+template <int KD>  // KD = k / 512: dwords of x per lane = 4 KD
+__global__ __launch_bounds__(1024) void lm_head_argmax_kernel(const LmHeadParams p) {
+    __shared__ __attribute__((aligned(16))) uint16_t xs[KD * 512];
+    __shared__ float red[32];
+    __shared__ unsigned flag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = KD * 512;
+    // ---- x = fp16(rmsnorm(h) * w): every workgroup for itself (16 KiB from L2)
+    float ss = 0.f;
+    for (int i = tid; i < k; i += 1024) {
+        const float v = p.h[i];
+        ss += v * v;
+    }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; w++) tot += red[w];
+    const float inv = p.rms_eps > 0.f ? __builtin_amdgcn_rsqf(tot / (float)k + p.rms_eps) : 1.0f;
+    for (int i = tid; i < k; i += 1024) {
+        const _Float16 xn = (_Float16)(p.h[i] * inv);  // the norm's output dtype is fp16 (HF LlamaRMSNorm), then * weight
+        const _Float16 xw = p.rms_w ? xn * __builtin_bit_cast(_Float16, p.rms_w[i]) : xn;
+        xs[i] = __builtin_bit_cast(uint16_t, xw);
+    }
+    __syncthreads();
+    u32x4 xr[KD];
+#pragma unroll
+    for (int c = 0; c < KD; c++) xr[c] = *reinterpret_cast<const u32x4 *>(xs + c * 512 + 8 * lane);
+    // ---- rows
+    const int gw = blockIdx.x * 16 + wave, nw = gridDim.x * 16;
+    float best = -3.0e38f;
+    int besti = 0x7fffffff;
+    const gptr<const uint16_t> W = as_global(p.w);
+    for (int r0 = gw; r0 < p.vocab; r0 += 2 * nw) {
+        u32x4 wv[2][KD];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int r = r0 + u * nw;
+            const gptr<const uint16_t> row = W + (long)(r < p.vocab ? r : r0) * k + 8 * lane;
+#pragma unroll
+            for (int c = 0; c < KD; c++) wv[u][c] = __builtin_nontemporal_load((gptr<const u32x4>)(row + c * 512));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int r = r0 + u * nw;
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < KD; c++) {
+                a = fdot2(wv[u][c].x, xr[c].x, a);
+                a = fdot2(wv[u][c].y, xr[c].y, a);
+                a = fdot2(wv[u][c].z, xr[c].z, a);
+                a = fdot2(wv[u][c].w, xr[c].w, a);
+            }
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) a += __shfl_xor(a, sh, 64);
+            if (r < p.vocab) {
+                if (p.logits && lane == 0) p.logits[r] = a;
+                if (a > best) best = a, besti = r;  // rows ascend within a wave: strict > keeps the lowest index
+            }
+        }
+    }
+    // ---- workgroup argmax, partial out, ticket, final reduction by the last arriver
+    if (lane == 0) {
+        red[wave] = best;
+        red[16 + wave] = __builtin_bit_cast(float, besti);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float b = red[0];
+        int bi = __builtin_bit_cast(int, red[16]);
+        for (int w = 1; w < 16; w++) {
+            const float v = red[w];
+            const int vi = __builtin_bit_cast(int, red[16 + w]);
+            if (v > b || (v == b && vi < bi)) b = v, bi = vi;
+        }
+        __hip_atomic_store(as_global(reinterpret_cast<unsigned *>(p.ws + 2 * blockIdx.x)), __builtin_bit_cast(unsigned, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(as_global(reinterpret_cast<unsigned *>(p.ws + 2 * blockIdx.x + 1)), (unsigned)bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned *ticket = reinterpret_cast<unsigned *>(p.ws + 2 * gridDim.x);
+        const unsigned t = __hip_atomic_fetch_add(as_global(ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag = t == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (flag == 0u) return;
+    float b = -3.0e38f;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < (int)gridDim.x; i += 1024) {
+        const float v = __builtin_bit_cast(float, __hip_atomic_load(as_global(reinterpret_cast<const unsigned *>(p.ws + 2 * i)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const int vi = (int)__hip_atomic_load(as_global(reinterpret_cast<const unsigned *>(p.ws + 2 * i + 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v > b || (v == b && vi < bi)) b = v, bi = vi;
+    }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        const float ob = __shfl_xor(b, sh, 64);
+        const int oi = __shfl_xor(bi, sh, 64);
+        if (ob > b || (ob == b && oi < bi)) b = ob, bi = oi;
+    }
+    if (lane == 0) {
+        red[wave] = b;
+        red[16 + wave] = __builtin_bit_cast(float, bi);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 0; w < 16; w++) {
+            const float v = red[w];
+            const int vi = __builtin_bit_cast(int, red[16 + w]);
+            if (v > b || (v == b && vi < bi)) b = v, bi = vi;
+        }
+        *p.token = bi;
+        __hip_atomic_store(as_global(reinterpret_cast<unsigned *>(p.ws + 2 * gridDim.x)), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace qpal
 
 using namespace qpal;
@@ -693,4 +825,29 @@ extern "C" int qpal_attn_rope_decode(const float *q, const float *k, const float
     if (hd == 64) return launch_attn(attn_rope_decode_kernel<64>, p, nq, 1024, lds, stream);
     if (hd == 128) return launch_attn(attn_rope_decode_kernel<128>, p, nq, 1024, lds, stream);
     return launch_attn(attn_rope_decode_kernel<256>, p, nq, 1024, lds, stream);
+}
+
+// workspace of qpal_lm_head_argmax: one (max, index) pair per workgroup + the ticket
+static int lm_head_grid(int vocab) {
+    int g = (vocab + 31) / 32;  // >= 2 rows per wave
+    return g < 1 ? 1 : g > 1024 ? 1024 : g;
+}
+extern "C" long qpal_lm_head_ws_bytes(int vocab) { return vocab > 0 ? (2L * lm_head_grid(vocab) + 1) * 4 : 0; }
+
+extern "C" int qpal_lm_head_argmax(const float *h_f32, const void *rms_w_f16, float rms_eps, const void *w_f16, float *logits_f32,
+                                   long *token, void *ws, long ws_bytes, int vocab, int k, void *stream) {
+    if (!h_f32 || !w_f16 || !token || !ws) return QPAL_E_NULL;
+    if (vocab < 1 || (k != 2048 && k != 4096 && k != 8192)) return QPAL_E_SHAPE;
+    if (ws_bytes < qpal_lm_head_ws_bytes(vocab)) return QPAL_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(w_f16) & 15) || (reinterpret_cast<uintptr_t>(ws) & 3) || (reinterpret_cast<uintptr_t>(h_f32) & 3) ||
+        (rms_w_f16 && (reinterpret_cast<uintptr_t>(rms_w_f16) & 1)))
+        return QPAL_E_ALIGN;
+    LmHeadParams p{h_f32, static_cast<const uint16_t *>(rms_w_f16), rms_eps > 0.f ? rms_eps : 0.f, static_cast<const uint16_t *>(w_f16),
+                   logits_f32, token, static_cast<float *>(ws), vocab, k};
+    const int grid = lm_head_grid(vocab);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (k == 2048) hipLaunchKernelGGL(lm_head_argmax_kernel<4>, dim3(grid), dim3(1024), 0, s, p);
+    else if (k == 4096) hipLaunchKernelGGL(lm_head_argmax_kernel<8>, dim3(grid), dim3(1024), 0, s, p);
+    else hipLaunchKernelGGL(lm_head_argmax_kernel<16>, dim3(grid), dim3(1024), 0, s, p);
+    return (int)hipGetLastError();
 }

@@ -203,6 +203,49 @@ def test_rmsnorm_inside_the_rotation_launch(qp, n):
     assert torch.allclose(got, ref, atol=tol, rtol=4e-3), float((got - ref).abs().max())
 
 
+@pytest.mark.parametrize("vocab,k,eps", [(128256, 4096, 1e-5), (32000, 2048, 0.0), (1000, 8192, 1e-5), (33, 4096, 1e-5)])
+def test_lm_head_argmax_one_launch(qp, vocab, k, eps):
+    """qpal_lm_head_argmax: final RMSNorm + fp16 lm_head GEMV + argmax (+ optional logits) against plain torch; twice (the
+    ticket of the last-arriver reduction must be back at zero); ties take the lowest index like torch.argmax."""
+    dev = torch.device("cuda", 0)
+    nat = qp._native
+    gen = torch.Generator(device=dev).manual_seed(vocab)
+    h = torch.randn(k, device=dev, generator=gen) * 2.0
+    w_ln = (1.0 + 0.1 * torch.randn(k, device=dev, generator=gen)).half()
+    W = (torch.randn(vocab, k, device=dev, generator=gen) * 0.05).half()
+    wsb = nat.lib().qpal_lm_head_ws_bytes(vocab)
+    ws = torch.zeros(wsb // 4, device=dev)
+    logits = torch.empty(vocab, device=dev)
+    tok = torch.full((1,), -1, dtype=torch.long, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    if eps > 0:
+        x = (h * torch.rsqrt((h * h).mean() + eps)).half() * w_ln
+    else:
+        x = h.half()
+    ref = W.float() @ x.float()
+    for rep in range(2):
+        tok.fill_(-1)
+        nat.check(nat.lib().qpal_lm_head_argmax(h.data_ptr(), w_ln.data_ptr() if eps > 0 else None, eps, W.data_ptr(),
+                                                logits.data_ptr() if rep == 0 else None, tok.data_ptr(), ws.data_ptr(), wsb, vocab, k,
+                                                stream), "qpal_lm_head_argmax")
+        torch.cuda.synchronize()
+        t = int(tok[0])
+        assert 0 <= t < vocab
+        tol = 2e-3 * float(ref.abs().max())  # x rounds once more or less than torch's fp16 pipeline; fp32 dot vs fp32 matmul
+        assert float(ref[t]) >= float(ref.max()) - tol
+        if rep == 0:
+            assert torch.allclose(logits, ref, atol=tol, rtol=1e-3)
+            assert t == int(logits.argmax())
+    # exact ties: rows 7 and 500 (and the last row) are copies of the winner
+    if vocab > 600:
+        W2 = W.clone()
+        W2[7] = W[t]; W2[500] = W[t]; W2[vocab - 1] = W[t]
+        nat.check(nat.lib().qpal_lm_head_argmax(h.data_ptr(), w_ln.data_ptr() if eps > 0 else None, eps, W2.data_ptr(), None, tok.data_ptr(),
+                                                ws.data_ptr(), wsb, vocab, k, stream), "qpal_lm_head_argmax")
+        torch.cuda.synchronize()
+        assert int(tok[0]) == min(7, t)
+
+
 @pytest.mark.parametrize("model", ["3_8b", "3_70b"])
 def test_fused_decode_step_matches_modular_step(qp, model):
     """perf/decode_llama.py: the fused-glue step (6 launches per layer; 9 where the hidden width's rotation cannot run inside the
