@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define QPAL_VERSION 210
+#define QPAL_VERSION 220
 
 #define QPAL_OK 0
 #define QPAL_E_SHAPE (-1)   /* m, k, n outside the supported set (m%32, k%32, 1<=n<=64 ...) */
