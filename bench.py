@@ -80,6 +80,9 @@ def parse_args():
                     help="qdict workloads: tensor-core-order vs SIMT packing of the VQ/SQ layers as published (chosen from the "
                          "reference's RTX 4090 latency table) or re-chosen from this GPU's table (perf/latency/)")
     ap.add_argument("--no-kind-breakdown", action="store_true", help="skip the per-launch-kind timing of the default run")
+    ap.add_argument("--no-swiglu-epilogue", action="store_true",
+                    help="--incoherent: up|gate as fp32 outputs and SwiGLU inside the rotation launch (default: interleaved up|gate layer, "
+                         "SwiGLU in the GEMV epilogue)")
     ap.add_argument("--no-incoherent-extra", action="store_true",
                     help="skip the second figure (token with the incoherence wrapper) of the default run")
     ap.add_argument("--no-fuse-rotation", action="store_true",
@@ -419,6 +422,15 @@ def main():
                     "hadK": None if hadK is None else hadK.T.contiguous().half().to(device), "K": K,
                     "wscale": [(0.01 + 0.02 * torch.rand(m.out_features, device=device, generator=gen)).half()
                                for m, _, _ in grp]})
+                mods = [m for m, _, _ in grp]
+                if (len(per) == 3 and n == 1 and K == 1 and not args.no_fuse_rotation and not args.no_swiglu_epilogue
+                        and len(mods) == 2 and type(mods[0]) is type(mods[1]) and qp.linear.rotation_fusable(mods, n)
+                        and type(mods[0]) in qp.linear._PACKED_KEYS and mods[0].out_features == mods[1].out_features
+                        and qp.linear._codec_key(mods[0]) == qp.linear._codec_key(mods[1])):
+                    gate, up = mods  # the group is (gate, up)
+                    per[-1]["il"] = qp.linear.interleave_up_gate(up, gate)
+                    per[-1]["il_w"] = qp.linear.interleave_rows(per[-1]["wscale"][1], per[-1]["wscale"][0])
+                    qp.share_codebooks([per[-1]["il"], up, gate])
             inc.append(per)
 
     if args.incoherent:
@@ -440,9 +452,20 @@ def main():
                 if gi == 2 and len(mods) == 2:  # the group is (gate, up); the SwiGLU rotation reads up | gate
                     mods, wsc = mods[::-1], wsc[::-1]
                 kw = dict(wscales=wsc, oscale=scale)
+                if gi == 2 and "il" in pi:
+                    # up | gate as one layer with interleaved supertile rows: the launch writes fp16 silu(gate) * up itself
+                    act = torch.empty((n, pi["il"].out_features // 2), dtype=torch.float16, device=device)
+                    nxt = groups[3][0][0].out_features
+                    if not args.no_prezero:
+                        pre[3] = torch.empty((n, nxt), dtype=torch.float32, device=device)
+                    qp.multi_gemv([pi["il"]], xs[grp[0][1]], wscales=[pi["il_w"]], oscale=scale, x_rot=(pi["su"], 1 / scale),
+                                  prezero=pre.get(3), act_out=act)
+                    ug = act
+                    outs.append(act)
+                    continue
                 if gi == 3:
                     xr = had.rotate(ug, hadK=pi["hadK"], K=pi["K"], su=pi["su"], post_scale=1 / scale,
-                                    in_mode=had.IN_SWIGLU_F32)
+                                    in_mode=had.IN_F16 if ug.dtype == torch.float16 else had.IN_SWIGLU_F32)
                 elif pi["K"] == 1 and not args.no_fuse_rotation and qp.linear.rotation_fusable(mods, n):
                     xr = xs[grp[0][1]]
                     kw["x_rot"] = (pi["su"], 1 / scale)

@@ -92,6 +92,11 @@ typedef struct qpal_tcq_job {
     int kv2;           /* with kv != 0 and c2 != NULL: a COLUMN-SPLIT (combt) layer inside an any-KV launch — stream 1 (columns
                           [0, k/2)) at kv, stream 2 at kv2 bits, both of the call's S; the call's split stays NONE.  tcomb and
                           tcq projections of a mixed-scheme model then share one launch.  0: single stream */
+    void *act_out;     /* fp16 [m / 2] or NULL.  Non-NULL (needs x_had, batch 1): the layer is an up | gate pair whose supertile
+                          rows (32 output rows) ALTERNATE up, gate, up, gate ... (qpalette_amd.linear.interleave_up_gate builds
+                          it from the two layers); the epilogue then writes fp16(silu(fp16 gate)) * fp16 up — the
+                          `act_fn(gate) * up` of lib/linear/incoherent_linear.py:333 — here and `out` is not written
+                          (may be NULL).  The following rotation reads 2 bytes per element instead of 8 and evaluates no SwiGLU */
 } qpal_tcq_job;
 /* prezero/prezero_bytes (may be NULL/0): a buffer this launch also fills with zeros, for a LATER launch on the
  * same stream that accumulates into it with atomics (split-K of a few-rows x long-K layer such as down_proj).
@@ -130,6 +135,7 @@ typedef struct qpal_lut_job {
     float x_rms_eps;      /* as in qpal_tcq_job */
     const void *x_rms_w;
     int accumulate;
+    void *act_out;     /* as in qpal_tcq_job */
 } qpal_lut_job;
 int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits, int vec, void *prezero,
                            long prezero_bytes, void *stream);

@@ -106,6 +106,7 @@ def main(argv=None):
     ap.add_argument("--start-pos", type=int, default=8, help="position of the first timed token (the cache below it is attended over)")
     ap.add_argument("--vocab", type=int, default=128256)
     ap.add_argument("--no-fused", action="store_true", help="skip the fused-glue step (third figure)")
+    ap.add_argument("--no-swiglu-epilogue", action="store_true", help="fused step: up|gate as fp32 outputs + SwiGLU inside the rotation launch")
     ap.add_argument("--torch-lm-head", action="store_true", help="fused step: final norm, lm_head and argmax as torch ops (hipBLASLt GEMV)")
     ap.add_argument("--no-split-attention", action="store_true", help="one workgroup per query head at every context length")
     ap.add_argument("--no-modular", action="store_true", help="time the fused-glue step only (profiling)")
@@ -192,6 +193,7 @@ def main(argv=None):
     a16 = torch.zeros(1, H, dtype=torch.float16, device=dev)
     qkv32 = torch.zeros(1, H + 2 * kv_out, dtype=torch.float32, device=dev)
     ug32 = torch.zeros(1, 2 * I, dtype=torch.float32, device=dev)
+    act16 = torch.zeros(1, I, dtype=torch.float16, device=dev)
     eps = layers[0].input_layernorm.eps
     # long caches: split-context attention (one workspace serves every layer: launches are stream-ordered)
     attn_ws_bytes = 0 if args.no_split_attention else nat.lib().qpal_attn_ws_bytes(nq, nkv, head_dim, args.context)
@@ -242,6 +244,19 @@ def main(argv=None):
         else:
             ugl, ugw = [mlp.up_proj, mlp.gate_proj], [mlp.Wscale_ug[:inter], mlp.Wscale_ug[inter:]]
         ug_outs = list(ug32.split([l.out_features for l in ugl], dim=1))
+        if rot_in_gemv and not args.no_swiglu_epilogue:
+            # up | gate as ONE layer with interleaved supertile rows: the launch's epilogue writes fp16 silu(gate) * up itself
+            if not hasattr(mlp, "_ug_il"):
+                il = qp.linear.interleave_up_gate(mlp.ug_proj, None) if mlp.merge_ug else qp.linear.interleave_up_gate(mlp.up_proj, mlp.gate_proj)
+                qp.share_codebooks([il, mlp.down_proj] + ugl)
+                mlp._ug_il = il
+                mlp._ug_il_w = qp.linear.interleave_rows(mlp.Wscale_ug[:inter], mlp.Wscale_ug[inter:])
+            qp.multi_gemv([mlp._ug_il], h32, wscales=[mlp._ug_il_w], oscale=mlp.scale, x_rot=(mlp.SU_ug, 1.0 / mlp.scale),
+                          x_rms=(eps, layer.post_attention_layernorm.weight), act_out=act16)
+            xr = qp.hadamard.rotate(act16, hadK=mlp.had_left_dp_T, K=mlp.inter_K, su=mlp.SU_dp, post_scale=1.0 / mlp.scale)
+            qp.multi_gemv([mlp.down_proj], xr, outs=[h32], outs_zeroed=True, wscales=[mlp.Wscale_dp], oscale=mlp.scale,
+                          accumulate=True)
+            return
         if rot_in_gemv:
             qp.multi_gemv(ugl, h32, outs=ug_outs, wscales=ugw, oscale=mlp.scale, x_rot=(mlp.SU_ug, 1.0 / mlp.scale),
                           x_rms=(eps, layer.post_attention_layernorm.weight))

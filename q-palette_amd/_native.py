@@ -21,7 +21,7 @@ class TcqJob(ctypes.Structure):
                 ("out_zeroed", _I), ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long),
                 ("x_had", _I), ("x_post", _F), ("x_su", _P), ("kv", _I),
                 ("x_f32", _P), ("x_f32_scale", _F), ("x_fresh", _I), ("publish", _I),
-                ("x_rms_eps", _F), ("x_rms_w", _P), ("accumulate", _I), ("kv2", _I)]
+                ("x_rms_eps", _F), ("x_rms_w", _P), ("accumulate", _I), ("kv2", _I), ("act_out", _P)]
 
 
 class LutJob(ctypes.Structure):
@@ -29,7 +29,7 @@ class LutJob(ctypes.Structure):
     _fields_ = [("out", _P), ("qweight", _P), ("x", _P), ("lut", _P), ("m", _I), ("k", _I), ("out_zeroed", _I),
                 ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long), ("x_had", _I), ("x_post", _F), ("x_su", _P),
                 ("x_f32", _P), ("x_f32_scale", _F), ("x_fresh", _I), ("publish", _I),
-                ("x_rms_eps", _F), ("x_rms_w", _P), ("accumulate", _I)]
+                ("x_rms_eps", _F), ("x_rms_w", _P), ("accumulate", _I), ("act_out", _P)]
 
 
 class ChainPhase(ctypes.Structure):

@@ -134,13 +134,16 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves 
     while (log2_wpr > 0 && items_at(mp, log2_wpr, waves) > kNumCU) log2_wpr--;
     while (log2_wpr > 0 && (1 << log2_wpr) > min_st) log2_wpr--;   // no more waves per row than steps
     if (two && log2_wpr == 0) log2_wpr = 1;                         // a combt row needs >= 2 chunks
+    bool pairs = false;  // a SwiGLU-epilogue job: two supertile rows (up, gate) per workgroup at least, no split-K
+    for (int j = 0; j < mp.njobs; j++) pairs = pairs || mp.job[j].act_out != nullptr;
+    if (pairs && log2_wpr == log2w) log2_wpr = log2w - 1;
     if (force_wpr >= 0 && force_wpr <= log2w) log2_wpr = force_wpr;
     const int items = items_at(mp, log2_wpr, waves);
     for (int j = 0; j < mp.njobs; j++) {
         TcParams &p = mp.job[j];
         int sk = 1;
         const int per_wave = (p.st1 + p.st2 + (1 << log2_wpr) - 1) >> log2_wpr;
-        if (items * 2 <= kNumCU && log2_wpr == log2w) {
+        if (items * 2 <= kNumCU && log2_wpr == log2w && !pairs) {
             // idle CUs: share each row's K range between workgroups if the waves have steps to give away
             const int want = kNumCU / items;
             const int min_steps = (out_zeroed && out_zeroed[j]) ? 2 : 6;  // a memset node costs ~3 us
@@ -322,8 +325,9 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         int rc = job_two ? tcq_check(jb.c1, jb.c2, jb.tlut, jb.m, jb.k, S, kv, jb.kv2, QPAL_SPLIT_COLS)
                          : tcq_check(jb.c1, jb.c2, jb.tlut, jb.m, jb.k, S, kv, KV2, split);
         if (rc) return rc;
-        if (!jb.out || (!jb.x && !(jb.x_f32 && jb.x_had))) return QPAL_E_NULL;
+        if ((!jb.out && !jb.act_out) || (!jb.x && !(jb.x_f32 && jb.x_had))) return QPAL_E_NULL;
         if (jb.x_f32 && !jb.x_had) return QPAL_E_PARAM;  // fp32 input: rotation staging (or chain launches) only
+        if (jb.act_out && (!jb.x_had || n != 1 || jb.accumulate || (jb.m % 64) || !aligned(jb.act_out, 2))) return QPAL_E_PARAM;
         if ((jb.x && !aligned(jb.x, 8)) || !aligned(jb.out, 4) || (jb.k % 4)) return QPAL_E_ALIGN;
         if (jb.wscale && !aligned(jb.wscale, 2)) return QPAL_E_ALIGN;
         if (jb.ldo != 0 && jb.ldo < jb.m) return QPAL_E_SHAPE;
@@ -338,7 +342,8 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         rc = set_rotation(mp.job[j], jb.x_had, jb.x_su, jb.x_post, n, jb.k, jb.x_f32, jb.x_rms_eps, jb.x_rms_w);
         if (rc) return rc;
         mp.job[j].accumulate = jb.accumulate ? 1 : 0;
-        zeroed[j] = jb.out_zeroed;
+        mp.job[j].act_out = static_cast<uint16_t *>(jb.act_out);
+        zeroed[j] = jb.act_out ? 1 : jb.out_zeroed;  // (nothing to zero: `out` is not written; split-K is refused below)
     }
     // the kernel stages (or rotates) x once per distinct x pointer: jobs that share x must agree on how
     for (int j = 1; j < njobs; j++)
@@ -363,6 +368,10 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
             if (jobs[j].x_had) return QPAL_E_SHAPE;  // fused rotation: batch 1
     plan_launch(mp, zeroed, grid, waves_of(nbg));
     for (int j = 0; j < njobs; j++) {
+        if (mp.job[j].act_out) {  // the SwiGLU epilogue pairs two supertile rows of one workgroup and has no split-K form
+            if (mp.job[j].sk != 1 || (waves_of(nbg) >> mp.job[j].log2_wpr) < 2) return QPAL_E_SHAPE;
+            continue;
+        }
         int rc = zero_if_split(mp.job[j], jobs[j].m, s, jobs[j].out_zeroed);
         if (rc) return rc;
     }
@@ -448,16 +457,18 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
     int zeroed[kMaxJobs] = {0};
     for (int j = 0; j < njobs; j++) {
         const qpal_lut_job &jb = jobs[j];
-        int rc = lut_args_ok(jb.out, jb.qweight, jb.x ? jb.x : (jb.x_had ? jb.x_f32 : nullptr), jb.lut, jb.m, n, jb.k, bits, vec);
+        int rc = lut_args_ok(jb.out ? jb.out : jb.act_out, jb.qweight, jb.x ? jb.x : (jb.x_had ? jb.x_f32 : nullptr), jb.lut, jb.m, n, jb.k, bits, vec);
         if (rc) return rc;
         if (jb.x_f32 && !jb.x_had) return QPAL_E_PARAM;  // fp32 input: rotation staging (or chain launches) only
+        if (jb.act_out && (!jb.x_had || n != 1 || jb.accumulate || (jb.m % 64) || !aligned(jb.act_out, 2))) return QPAL_E_PARAM;
         if (jb.wscale && !aligned(jb.wscale, 2)) return QPAL_E_ALIGN;
         if (jb.ldo != 0 && jb.ldo < jb.m) return QPAL_E_SHAPE;
         lut_fill(mp.job[j], jb.out, jb.ldo ? jb.ldo : jb.m, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k, jb.wscale, jb.oscale);
         rc = set_rotation(mp.job[j], jb.x_had, jb.x_su, jb.x_post, n, jb.k, jb.x_f32, jb.x_rms_eps, jb.x_rms_w);
         if (rc) return rc;
         mp.job[j].accumulate = jb.accumulate ? 1 : 0;
-        zeroed[j] = jb.out_zeroed;
+        mp.job[j].act_out = static_cast<uint16_t *>(jb.act_out);
+        zeroed[j] = jb.act_out ? 1 : jb.out_zeroed;
     }
     for (int j = 1; j < njobs; j++)
         for (int i = 0; i < j; i++)
@@ -473,6 +484,10 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
     if (nbg == 8 && lut_image_bytes(bits, vec) > 64 * 1024) return QPAL_E_SHAPE;
     plan_launch(mp, zeroed, grid, waves_of(nbg));
     for (int j = 0; j < njobs; j++) {
+        if (mp.job[j].act_out) {
+            if (mp.job[j].sk != 1 || (waves_of(nbg) >> mp.job[j].log2_wpr) < 2) return QPAL_E_SHAPE;
+            continue;
+        }
         int rc = zero_if_split(mp.job[j], jobs[j].m, s, jobs[j].out_zeroed);
         if (rc) return rc;
     }

@@ -73,6 +73,8 @@ struct TcParams {
     float x_rms_eps;         // > 0: x <- x * rsqrt(mean(x^2) + eps) (* x_rms_w) before the sign flip (fp32, then ONE fp16 rounding)
     const uint16_t *x_rms_w; // fp16 [k] RMSNorm weight or null
     int accumulate;          // out += result instead of out = result
+    uint16_t *act_out;       // ROT kernels, batch 1: the layer's supertile rows alternate up / gate (u0 g0 u1 g1 ...): the epilogue
+                             // writes fp16 silu(gate) * up [m / 2] here instead of `out` (rows per workgroup >= 2, no split-K)
 };
 
 constexpr int kMaxJobs = 8;
@@ -795,9 +797,24 @@ __global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const u
         if (tid < (32 << log2_rpw)) {
             const int r = tid & 31, rl = tid >> 5;
             const int srow = (rg << log2_rpw) + rl;
+            [[maybe_unused]] bool continue_item = false;
             if (srow < p.nrows) {
                 // the incoherent wrappers' `* Wscale * scale`, fused
                 const float osc = p.wscale ? p.oscale * (float)__builtin_bit_cast(_Float16, (uint16_t)wraw) : p.oscale;
+                if constexpr (ROT) {
+                    if (p.act_out) {  // SwiGLU of an interleaved up | gate layer: threads (rl, r) and (rl + 1, r) are lanes r, r + 32
+                        float v = 0.f;
+                        for (int qq = 0; qq < wpr; qq++) v += red[((rl << p.log2_wpr) + qq) * 32 + r];
+                        const float mine = (float)(_Float16)(v * osc);           // the reference's fp16 up / gate
+                        const float gate = __shfl_down(mine, 32, 64);
+                        if ((rl & 1) == 0) {
+                            const float sg = (float)(_Float16)(gate * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gate * -1.44269504f)));
+                            p.act_out[(long)(srow >> 1) * 32 + r] = __builtin_bit_cast(uint16_t, (_Float16)(sg * mine));
+                        }
+                        continue_item = true;
+                    }
+                }
+                if (!continue_item)
                 for (int b = 0; b < p.n; b++) {
                     float v = 0.f;
                     for (int qq = 0; qq < wpr; qq++) v += red[(((rl << p.log2_wpr) + qq) * p.n + b) * 32 + r];

@@ -1,6 +1,8 @@
 """nn.Module mirror of the reference's quantized linears (lib/linear/{tcq,comb,vq}_linear.py)."""
 import os
 
+import torch
+
 from .comb_linear import CombLinearTCQ, CombtLinearTCQ
 from .tcq_linear import QTIPLinearTCQ
 from .vq_linear import VQLinearPackSIMT, VQLinearPackTensorCore
@@ -122,6 +124,41 @@ def launch_groups(layers, mixed_kv=False, mixed_family=None):
     return out
 
 
+_PACKED_KEYS = {QTIPLinearTCQ: ("trellis",), CombtLinearTCQ: ("trellis1", "trellis2"), VQLinearPackTensorCore: ("qweight",)}
+
+
+def interleave_up_gate(up, gate):
+    """One layer whose supertile rows (32 output rows) alternate up, gate, up, gate, ...: what the GEMV's SwiGLU epilogue needs
+    (multi_gemv(..., act_out=...): both halves of `act_fn(gate) * up` then live in the same workgroup).  up / gate: two
+    tensor-core-order layers of one codec and shape (or a merged up|gate layer as `up`, gate=None: rows [up; gate]).  A
+    supertile row is contiguous in every packed buffer, so this is a row shuffle of the packed data.  Returns the new layer;
+    use interleave_rows() on per-row vectors (Wscale)."""
+    if gate is None:
+        info = up._info()
+        m = info["out_features"]
+        keys = _PACKED_KEYS[type(up)]
+        halves = {key: info[key].reshape(m // 32, -1) for key in keys}
+        for key in keys:
+            t = halves[key]
+            info[key] = torch.stack([t[: m // 64], t[m // 64:]], dim=1).reshape(info[key].shape).contiguous()
+        return type(up).gen_layer_from_info(info).to(next(up.buffers()).device)
+    assert type(up) is type(gate) and _codec_key(up) == _codec_key(gate) and up.out_features == gate.out_features
+    iu, ig = up._info(), gate._info()
+    m = iu["out_features"]
+    info = dict(iu)
+    info["out_features"] = 2 * m
+    for key in _PACKED_KEYS[type(up)]:
+        a, b = iu[key].reshape(m // 32, -1), ig[key].reshape(m // 32, -1)
+        info[key] = torch.stack([a, b], dim=1).reshape(2 * iu[key].shape[0], *iu[key].shape[1:]).contiguous()
+    return type(up).gen_layer_from_info(info).to(next(up.buffers()).device)
+
+
+def interleave_rows(up_vec, gate_vec):
+    """Per-output-row vectors (Wscale) of an up / gate pair in the row order of interleave_up_gate."""
+    m = up_vec.numel()
+    return torch.stack([up_vec.reshape(m // 32, 32), gate_vec.reshape(m // 32, 32)], dim=1).reshape(-1).contiguous()
+
+
 def rotation_fusable(layers, n):
     """True if multi_gemv(..., x_rot=...) can apply the left rotation inside the GEMV launches of `layers`."""
     from .. import ops
@@ -130,7 +167,7 @@ def rotation_fusable(layers, n):
 
 
 def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=None, oscale=1.0, x_rot=None, x_rms=None,
-               accumulate=False):
+               accumulate=False, act_out=None):
     """y_i = layers[i](x) for several quantized linears that share the input, batch <= 8.  Layers of one
     kind and codec (e.g. q|k|v or gate|up of one block) go out as ONE kernel launch per codec
     (C-ABI qpal_*_gemv_multi); anything else is one launch per layer.  Returns fp32/fp16 [n, m_i] tensors in
@@ -144,11 +181,28 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
     x_rot = (su, post_scale): x is the UN-rotated input and every launch stages fp16(fp16(H (x*su)/sqrt(k)) * post)
     itself (only where rotation_fusable(layers, n)); x may then be the fp32 residual stream, and x_rms = (eps, weight or
     None) applies the RMSNorm in front of the rotation (decoder-block fusion).  accumulate: outs[i] += y_i (the residual add:
-    outs[i] holds the residual stream; with outs_zeroed=True the launch may split K and add with atomics)."""
+    outs[i] holds the residual stream; with outs_zeroed=True the launch may split K and add with atomics).
+    act_out (fp16 [1, m / 2]; one layer built by interleave_up_gate, batch 1, x_rot): the launch's epilogue writes
+    silu(gate) * up there and no fp32 output (returns [None])."""
     from .. import ops
 
     x2 = x.reshape(-1, layers[0].in_features)
     n = x2.shape[0]
+    if act_out is not None:
+        if len(layers) != 1 or n != 1 or x_rot is None or accumulate or outs is not None:
+            raise RuntimeError("multi_gemv: act_out needs ONE interleaved up|gate layer, batch 1 and x_rot")
+        layer = layers[0]
+        common = dict(prezero=prezero, wscales=wscales, oscale=oscale, x_rot=x_rot, x_rms=x_rms, act_outs=[act_out])
+        if isinstance(layer, QTIPLinearTCQ):
+            ops.tcq_gemv_multi([(layer.trellis, None, layer.tlut, layer.out_features)], x2, layer.tlut_bits, layer.KV, **common)
+        elif isinstance(layer, CombtLinearTCQ) and layer.use_comb_kernel:
+            ops.tcq_gemv_multi([(layer.trellis1, layer.trellis2, layer.tlut, layer.out_features)], x2, layer.tlut_bits,
+                               layer.KV[0], layer.KV[1], split=2, **common)
+        elif isinstance(layer, VQLinearPackTensorCore):
+            ops.lut_tc_gemv_multi([(layer.qweight, layer.lut, layer.out_features)], x2, layer.lut_bits, layer.vec_sz, **common)
+        else:
+            raise RuntimeError("multi_gemv: act_out needs a tensor-core-order packed layer")
+        return [None]
     if n > min(l.max_fused_batch for l in layers):  # decode-to-fp16 + GEMM path of the modules: the fused-launch extras have no meaning there
         if outs is not None or prezero is not None or wscales is not None or oscale != 1.0 or x_rot is not None or accumulate:
             raise RuntimeError("multi_gemv: outs / prezero / wscales / oscale / x_rot need a fused batch (n <= 64)")

@@ -284,6 +284,16 @@ def _x_arg(x, x_rot):
     return _dev(x.to(torch.float16), "x"), None
 
 
+def _act_arg(act_outs, j, n, m, device):
+    """fp16 [1, m / 2] destination of the SwiGLU epilogue of job j (an interleaved up|gate layer), or None"""
+    if act_outs is None or act_outs[j] is None:
+        return None
+    a = act_outs[j]
+    _chk(n == 1 and a.is_cuda and a.device == device and a.dtype == torch.float16 and a.is_contiguous() and a.numel() == m // 2,
+         "act_out must be a contiguous fp16 tensor of m / 2 elements on the layer's device (batch 1)")
+    return a
+
+
 def _rms_args(x_rms, k):
     """x_rms = (eps, weight fp16 [k] or None): RMSNorm applied in front of the fused rotation."""
     if x_rms is None:
@@ -296,7 +306,7 @@ def _rms_args(x_rms, k):
 
 
 def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=False, prezero=None, wscales=None,
-                   oscale=1.0, x_rot=None, x_rms=None, accumulate=False):
+                   oscale=1.0, x_rot=None, x_rms=None, accumulate=False, act_outs=None):
     """Several TCQ GEMVs of one codec and one input in ONE launch (C-ABI qpal_tcq_gemv_multi).
     streams: list of (c1, c2_or_None, tlut, m), (c1, None, tlut, m, KV) or (c1, c2, tlut, m, KV, KV2): with per-stream KV, layers of
     one codebook size but different bit widths — single-stream and column-split (combt) ones — share the launch.  x: [n, k].  Returns the list of fp32 [n, m] outputs.
@@ -330,12 +340,14 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
             c2 = _dev(c2, "compressed2")
             _tcq_stream_ok(c1, m, k // 2, KV1, "compressed1")
             _tcq_stream_ok(c2, m, k // 2, KV2, "compressed2")
-        out = _out_arg(outs, j, n, m, x.device)
-        jobs[j] = nat.TcqJob(out.data_ptr(), c1.data_ptr(), c2.data_ptr() if c2 is not None else None,
+        act = _act_arg(act_outs, j, n, m, x.device)
+        out = None if act is not None else _out_arg(outs, j, n, m, x.device)
+        jobs[j] = nat.TcqJob(out.data_ptr() if out is not None else None, c1.data_ptr(), c2.data_ptr() if c2 is not None else None,
                              xh.data_ptr() if xh is not None else None, tl.data_ptr(), m, k,
                              1 if (outs is not None and outs_zeroed) else 0,
-                             _wscale_arg(wscales, j, m), float(oscale), _ldo(out, n, m), had, xpost, xsu, kv,
-                             x32.data_ptr() if x32 is not None else None, 1.0, 0, 0, rms_eps, rms_w, 1 if accumulate else 0, kv2)
+                             _wscale_arg(wscales, j, m), float(oscale), _ldo(out, n, m) if out is not None else 0, had, xpost, xsu, kv,
+                             x32.data_ptr() if x32 is not None else None, 1.0, 0, 0, rms_eps, rms_w, 1 if accumulate else 0, kv2,
+                             act.data_ptr() if act is not None else None)
         results.append(out)
         keep += [c1, c2, tl]
     zp, zb = _prezero_args(prezero)
@@ -346,7 +358,7 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
 
 
 def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezero=None, wscales=None, oscale=1.0,
-                      x_rot=None, x_rms=None, accumulate=False):
+                      x_rot=None, x_rms=None, accumulate=False, act_outs=None):
     """Several VQ/SQ (tensor-core packing) GEMVs of one codec and one input in ONE launch.
     layers: list of (qweight, lut, m); x: [n, k].  outs / outs_zeroed / prezero as in tcq_gemv_multi."""
     n, k = x.shape
@@ -359,11 +371,13 @@ def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezer
     results, keep = [], [xh, x32]
     for j, (q, lut, m) in enumerate(layers):
         q, cb = _lut_args(q, lut, m, k, bits, vec)
-        out = _out_arg(outs, j, n, m, x.device)
-        jobs[j] = nat.LutJob(out.data_ptr(), q.data_ptr(), xh.data_ptr() if xh is not None else None, cb.data_ptr(), m, k,
-                             1 if (outs is not None and outs_zeroed) else 0, _wscale_arg(wscales, j, m), float(oscale),
-                             _ldo(out, n, m), had, xpost, xsu, x32.data_ptr() if x32 is not None else None, 1.0, 0, 0,
-                             rms_eps, rms_w, 1 if accumulate else 0)
+        act = _act_arg(act_outs, j, n, m, x.device)
+        out = None if act is not None else _out_arg(outs, j, n, m, x.device)
+        jobs[j] = nat.LutJob(out.data_ptr() if out is not None else None, q.data_ptr(), xh.data_ptr() if xh is not None else None,
+                             cb.data_ptr(), m, k, 1 if (outs is not None and outs_zeroed) else 0, _wscale_arg(wscales, j, m),
+                             float(oscale), _ldo(out, n, m) if out is not None else 0, had, xpost, xsu,
+                             x32.data_ptr() if x32 is not None else None, 1.0, 0, 0, rms_eps, rms_w, 1 if accumulate else 0,
+                             act.data_ptr() if act is not None else None)
         results.append(out)
         keep += [q, cb]
     zp, zb = _prezero_args(prezero)
@@ -405,7 +419,7 @@ def mixed_gemv_multi(tcq_streams, lut_layers, x, S, outs=None, outs_zeroed=False
         out = _out_arg(outs, j, n, m, x.device)
         tj[j] = nat.TcqJob(out.data_ptr(), c1.data_ptr(), c2.data_ptr() if c2 is not None else None, xh.data_ptr(), tl.data_ptr(), m, k,
                            zeroed, _wscale_arg(wscales, j, m), float(oscale), _ldo(out, n, m), 0, 0.0, None, kv, None, 1.0, 0, 0,
-                           0.0, None, 0, kv2)
+                           0.0, None, 0, kv2, None)
         results.append(out)
         keep += [c1, c2, tl]
     bits_a, vec_a = (ctypes.c_int * len(lut_layers))(), (ctypes.c_int * len(lut_layers))()
@@ -414,7 +428,7 @@ def mixed_gemv_multi(tcq_streams, lut_layers, x, S, outs=None, outs_zeroed=False
         q, cb = _lut_args(q, lut, m, k, bits, vec)
         out = _out_arg(outs, nt + i, n, m, x.device)
         lj[i] = nat.LutJob(out.data_ptr(), q.data_ptr(), xh.data_ptr(), cb.data_ptr(), m, k, zeroed, _wscale_arg(wscales, nt + i, m),
-                           float(oscale), _ldo(out, n, m), 0, 0.0, None, None, 1.0, 0, 0, 0.0, None, 0)
+                           float(oscale), _ldo(out, n, m), 0, 0.0, None, None, 1.0, 0, 0, 0.0, None, 0, None)
         bits_a[i], vec_a[i] = bits, vec
         results.append(out)
         keep += [q, cb]

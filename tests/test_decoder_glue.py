@@ -203,6 +203,44 @@ def test_rmsnorm_inside_the_rotation_launch(qp, n):
     assert torch.allclose(got, ref, atol=tol, rtol=4e-3), float((got - ref).abs().max())
 
 
+@pytest.mark.parametrize("qstr,inter", [("tcomb_6_7_0.5_none_0.9", 14336), ("tcq_4_none_0.9", 1024), ("ldlq_2_8_none_1.0", 2048)])
+def test_swiglu_in_the_gemv_epilogue(qp, qstr, inter):
+    """An up | gate pair with interleaved supertile rows (linear.interleave_up_gate): the rotating GEMV launch writes
+    fp16 silu(gate) * up itself (act_out) — equal to the two projections + torch SwiGLU on the reference's fp16 rounding points."""
+    dev = torch.device("cuda", 0)
+    k = 4096
+    up = qp.make_linear_from_info(qstr, qp.mem_op.dummy_linear_info(k, inter, qstr, seed=5, codebook_seed=3)).to(dev)
+    gate = qp.make_linear_from_info(qstr, qp.mem_op.dummy_linear_info(k, inter, qstr, seed=6, codebook_seed=3)).to(dev)
+    qp.share_codebooks([up, gate])
+    il = qp.linear.interleave_up_gate(up, gate)
+    assert il.out_features == 2 * inter
+    gen = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn(1, k, device=dev, generator=gen).half()
+    su = (torch.randint(0, 2, (k,), device=dev, generator=gen) * 2 - 1).half()
+    wu = (0.02 + 0.02 * torch.rand(inter, device=dev, generator=gen)).half()
+    wg = (0.02 + 0.02 * torch.rand(inter, device=dev, generator=gen)).half()
+    scale = 32.0
+    u, g = qp.multi_gemv([up, gate], x, wscales=[wu, wg], oscale=scale, x_rot=(su, 1.0 / scale))
+    ref = (torch.nn.functional.silu(g.half().float()).half().float() * u.half().float()).half()
+    act = torch.full((1, inter), float("nan"), dtype=torch.float16, device=dev)
+    (none,) = qp.multi_gemv([il], x, wscales=[qp.linear.interleave_rows(wu, wg)], oscale=scale, x_rot=(su, 1.0 / scale), act_out=act)
+    torch.cuda.synchronize()
+    assert none is None and bool(torch.isfinite(act).all())
+    # same fp32 sums (the interleaved layer is planned like the pair), silu through the hardware reciprocal: <= 1-2 fp16 ulps
+    err = (act.float() - ref.float()).abs()
+    tol = 2.0 ** -9 * ref.float().abs() + 2.0 ** -9 * float(ref.float().abs().max()) * 2.0 ** -6
+    assert bool((err <= tol).all()), float((err / tol).max())
+    # and the rotation that follows reads it as plain fp16
+    hk, K = qp.hadamard.get_hadK(inter)
+    hkT = None if hk is None else hk.T.contiguous().half().to(dev)
+    sd = (torch.randint(0, 2, (inter,), device=dev, generator=gen) * 2 - 1).half()
+    a = qp.hadamard.rotate(act, hadK=hkT, K=K, su=sd, post_scale=1 / 8)
+    ug = torch.cat([u, g], dim=1)
+    b = qp.hadamard.rotate(ug, hadK=hkT, K=K, su=sd, post_scale=1 / 8, in_mode=qp.hadamard.IN_SWIGLU_F32)
+    torch.cuda.synchronize()
+    assert torch.allclose(a.float(), b.float(), atol=2.0 ** -8 * float(b.float().abs().max()), rtol=0)
+
+
 @pytest.mark.parametrize("vocab,k,eps", [(128256, 4096, 1e-5), (32000, 2048, 0.0), (1000, 8192, 1e-5), (33, 4096, 1e-5)])
 def test_lm_head_argmax_one_launch(qp, vocab, k, eps):
     """qpal_lm_head_argmax: final RMSNorm + fp16 lm_head GEMV + argmax (+ optional logits) against plain torch; twice (the
