@@ -90,6 +90,68 @@ def test_mixed_scheme_token_matches_oracle(env, workload, launch, packing):
         assert {"QTIPLinearTCQ", "CombtLinearTCQ"} <= kinds and kinds & {"VQLinearPackTensorCore", "VQLinearPackSIMT"}, kinds
 
 
+@gpu
+def test_full_size_token_properties(env):
+    """BASELINE.json configs[1] at FULL size (32 layers x 7 linears, 2.8 GB of packed weights: too big for the oracle's
+    dense decode) through size-independent properties of the path: linearity in x (small-integer inputs: x1 + x2 is exact in
+    fp16, so token(x1 + x2) = token(x1) + token(x2) up to fp32 summation), run-to-run determinism under HIP-graph replay, and
+    agreement of the three launch structures (one launch per linear, multi-job launches, one persistent chain kernel) — plus
+    the oracle on one linear of the LAST layer (so the model was built as specified all the way down)."""
+    bench, qp, oracle = env
+    device = torch.device("cuda", 0)
+    model_key, qstr = bench.WORKLOADS["llama3.1-8b_tcomb_6_7"]
+    torch.manual_seed(1234)
+    layers = bench.build_model(qp, torch, model_key, qstr, 32, device, keep_infos=True)
+    mods = [u for groups in layers for grp in groups for u in grp]
+    assert len(mods) == 224
+    gen = torch.Generator().manual_seed(11)
+
+    def inputs():
+        return {k: torch.randint(-3, 4, (1, k), generator=gen).half().to(device) for k in (4096, 14336)}
+
+    x1, x2 = inputs(), inputs()
+    x12 = {k: x1[k] + x2[k] for k in x1}
+    xs = {k: v.clone() for k, v in x1.items()}
+    token, _ = bench.make_token(qp, torch, layers, xs, 1, device, launch="multi")
+
+    def run(x):
+        for k in xs:
+            xs[k].copy_(x[k])
+        return [y.float().clone() for y in token()]
+
+    y1, y2, y12 = run(x1), run(x2), run(x12)
+    torch.cuda.synchronize()
+    for a, b, c in zip(y1, y2, y12):
+        scale = float(a.abs().max() + b.abs().max()) + 1e-30
+        assert torch.allclose(a + b, c, rtol=0, atol=2e-5 * scale)
+    # graph replay: the same bits every time
+    stream = torch.cuda.Stream(device)
+    with torch.cuda.stream(stream):
+        token()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            outs = token()
+        g.replay()
+        torch.cuda.synchronize()
+        first = [y.clone() for y in outs]
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(first, outs))
+    assert all(torch.allclose(a.float(), b, rtol=1e-4, atol=1e-4 * float(b.abs().max() + 1e-30)) for a, b in zip(first, y12))
+    # the other launch structures compute the same sums
+    for launch in ("single", "chain"):
+        tok2, _ = bench.make_token(qp, torch, layers, xs, 1, device, launch=launch)
+        alt = tok2()
+        torch.cuda.synchronize()
+        assert qp.chain.chain_error(device) == 0
+        for a, b in zip(alt, y12):
+            assert torch.allclose(a.float(), b, rtol=1e-4, atol=1e-4 * float(b.abs().max() + 1e-30)), launch
+    mod, k, info = mods[-1]  # down_proj of layer 31
+    _check(y12[-1], _oracle_weight(oracle, info), x12[k].cpu().numpy(), oracle)
+
+
 def test_mem3p25_average_bits():
     """The committed fixture is at 3.25 bits/weight (parameter-weighted), uses TCQ, VQ and SQ entries, no fusion."""
     import json
