@@ -169,6 +169,8 @@ def build_model(qp, torch, model_key, qstr, nlayers, device, shard=None, distinc
         layers.append([attn, [make(layer, [o])], mlp, [make(layer, [d])]])
     if not distinct_codebooks:  # what a checkpoint loader does: identical codebooks share one tensor
         qp.share_codebooks([m for groups in layers for grp in groups for m, _, _ in grp])
+    if os.environ.get("QPAL_BENCH_SHARED_WEIGHTS"):  # experiment knob, NOT a benchmark mode: every layer reads layer 0's buffers (88 MB:
+        layers = [layers[0]] * len(layers)          # resident in the 256 MB Infinity Cache) — what would cache-resident weights buy?
     return layers
 
 
