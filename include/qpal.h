@@ -84,8 +84,9 @@ typedef struct qpal_tcq_job {
      * the RMSNorm in front of it (lib/linear/incoherent_linear.py:76-108 is called on `input_layernorm(h)` by the model,
      * model/llama.py), and o_proj / down_proj add their result to it.  With x_had = 1: x_f32 (fp32 [k], 16-byte aligned) may
      * replace x; x_rms_eps > 0 normalises x <- x * rsqrt(mean(x^2) + eps) * x_rms_w (fp16 [k] or NULL) in fp32 before the
-     * fp16 rounding and the sign flip.  accumulate = 1 (any job): out += result (out is the residual stream; with
-     * out_zeroed = 1 the launch may split K and add with atomics).                                                     */
+     * fp16 rounding and the sign flip.  accumulate = 1 (any job): out += result (out is the residual stream).  The launch
+     * may split K on its own: the split-K atomics add onto the live contents of out, no memset is ever issued for an
+     * accumulating job, and out_zeroed is ignored for it (leave it 0: the buffer is NOT zero).                           */
     float x_rms_eps;
     const void *x_rms_w;
     int accumulate;

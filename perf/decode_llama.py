@@ -232,12 +232,12 @@ def main(argv=None):
                                                  torch.cuda.current_stream(dev).cuda_stream)
         nat.check(rc, "qpal_attn_rope_decode")
         if rot_in_gemv:
-            qp.multi_gemv([att.o_proj], a16, outs=[h32], outs_zeroed=True, wscales=[att.Wscale_o], oscale=att.scale,
+            qp.multi_gemv([att.o_proj], a16, outs=[h32], wscales=[att.Wscale_o], oscale=att.scale,
                           x_rot=(att.SU_o, 1.0 / att.scale), accumulate=True)
         else:
             hk, K = _hid(att, "_hadk_hidden")
             xr = qp.hadamard.rotate(a16, hadK=hk, K=K, su=att.SU_o, post_scale=1.0 / att.scale)
-            qp.multi_gemv([att.o_proj], xr, outs=[h32], outs_zeroed=True, wscales=[att.Wscale_o], oscale=att.scale, accumulate=True)
+            qp.multi_gemv([att.o_proj], xr, outs=[h32], wscales=[att.Wscale_o], oscale=att.scale, accumulate=True)
         inter = mlp.intermediate_size
         if mlp.merge_ug:
             ugl, ugw = [mlp.ug_proj], [mlp.Wscale_ug]
@@ -254,7 +254,7 @@ def main(argv=None):
             qp.multi_gemv([mlp._ug_il], h32, wscales=[mlp._ug_il_w], oscale=mlp.scale, x_rot=(mlp.SU_ug, 1.0 / mlp.scale),
                           x_rms=(eps, layer.post_attention_layernorm.weight), act_out=act16)
             xr = qp.hadamard.rotate(act16, hadK=mlp.had_left_dp_T, K=mlp.inter_K, su=mlp.SU_dp, post_scale=1.0 / mlp.scale)
-            qp.multi_gemv([mlp.down_proj], xr, outs=[h32], outs_zeroed=True, wscales=[mlp.Wscale_dp], oscale=mlp.scale,
+            qp.multi_gemv([mlp.down_proj], xr, outs=[h32], wscales=[mlp.Wscale_dp], oscale=mlp.scale,
                           accumulate=True)
             return
         if rot_in_gemv:
@@ -267,7 +267,7 @@ def main(argv=None):
             qp.multi_gemv(ugl, xr, outs=ug_outs, wscales=ugw, oscale=mlp.scale)
         xr = qp.hadamard.rotate(ug32, hadK=mlp.had_left_dp_T, K=mlp.inter_K, su=mlp.SU_dp, post_scale=1.0 / mlp.scale,
                                 in_mode=qp.hadamard.IN_SWIGLU_F32)
-        qp.multi_gemv([mlp.down_proj], xr, outs=[h32], outs_zeroed=True, wscales=[mlp.Wscale_dp], oscale=mlp.scale,
+        qp.multi_gemv([mlp.down_proj], xr, outs=[h32], wscales=[mlp.Wscale_dp], oscale=mlp.scale,
                       accumulate=True)
 
     def fused_step():

@@ -17,7 +17,17 @@ constexpr int kMaxBatch = 64;  // fused decode + GEMV / skinny GEMM: up to 8 MFM
 
 // MFMA column groups for a batch: 1, 2 (16 waves per workgroup), 4, 8 (8 waves: tc_kernels.h gemv_waves)
 int nbg_of(int n) { return n <= 8 ? 1 : n <= 16 ? 2 : n <= 32 ? 4 : 8; }
-int waves_of(int nbg) { return nbg >= 4 ? 8 : 16; }
+int waves_of(int nbg) { return gemv_waves<1>() == 8 ? 8 : (nbg >= 4 ? 8 : 16); }
+// workgroups one launch round can hold: one per CU; two with the 8-wave experiment build (tc_kernels.h QPAL_W8), whose
+// batch <= 16 kernels leave room for a second workgroup's LDS and registers
+int round_capacity(int waves) {
+#ifdef QPAL_W8
+    return waves == 8 ? 2 * kNumCU : kNumCU;   // (the wide-batch kernels use 256 VGPRs: they would also fit twice, LDS allowing)
+#else
+    (void)waves;
+    return kNumCU;
+#endif
+}
 
 inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
@@ -45,12 +55,17 @@ bool simt_ok(int bits, int vec) {
 // reduction buffer [16 waves][n][32] fp32 + x [n][k] fp16 must fit the kernel's LDS scratch
 int x_fits_lds(int n, int k) {
     static const int no_xlds = getenv("QPAL_NO_XLDS") != nullptr;
-    return !no_xlds && n <= 8 && 16 * 32 * 4 * n + 2 * n * k + 64 <= kScratchBytes && (n * k) % 8 == 0;
+    return !no_xlds && n <= 8 && gemv_waves<1>() * 32 * 4 * n + 2 * n * k + 64 <= kScratchBytes && (n * k) % 8 == 0;
 }
 
 // (k = 8192 would need the 8-row-tile transform: its registers do not fit the GEMV kernel's 128-VGPR budget)
 // and batch 1 only: the workgroup-wide transform needs 16 KiB of LDS beside x (larger batches: qpal_hadamard first)
-bool rot_ok(int n, int k) { return n == 1 && (k == 2048 || k == 4096) && x_fits_lds(n, k); }
+bool rot_ok(int n, int k) {
+#ifdef QPAL_W8
+    return false;  // the workgroup-wide transform is written for 16 waves
+#endif
+    return n == 1 && (k == 2048 || k == 4096) && x_fits_lds(n, k);
+}
 
 // x_had of a job -> kernel parameters; QPAL_E_SHAPE where the fused rotation is not available
 int set_rotation(TcParams &p, int x_had, const void *x_su, float x_post, int n, int k, const void *x_f32 = nullptr,
@@ -131,7 +146,8 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves 
     }
     const int log2w = waves == 16 ? 4 : 3;
     int log2_wpr = log2w;
-    while (log2_wpr > 0 && items_at(mp, log2_wpr, waves) > kNumCU) log2_wpr--;
+    const int cap = round_capacity(waves);
+    while (log2_wpr > 0 && items_at(mp, log2_wpr, waves) > cap) log2_wpr--;
     while (log2_wpr > 0 && (1 << log2_wpr) > min_st) log2_wpr--;   // no more waves per row than steps
     if (two && log2_wpr == 0) log2_wpr = 1;                         // a combt row needs >= 2 chunks
     bool pairs = false;  // a SwiGLU-epilogue job: two supertile rows (up, gate) per workgroup at least, no split-K
@@ -143,10 +159,11 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves 
         TcParams &p = mp.job[j];
         int sk = 1;
         const int per_wave = (p.st1 + p.st2 + (1 << log2_wpr) - 1) >> log2_wpr;
-        if (items * 2 <= kNumCU && log2_wpr == log2w && !pairs) {
+        if (items * 2 <= cap && log2_wpr == log2w && !pairs) {
             // idle CUs: share each row's K range between workgroups if the waves have steps to give away
-            const int want = kNumCU / items;
-            const int min_steps = (out_zeroed && out_zeroed[j]) ? 2 : 6;  // a memset node costs ~3 us
+            const int want = cap / items;
+            // a memset node costs ~3 us; an accumulating job needs none (its atomics add onto the live output)
+            const int min_steps = ((out_zeroed && out_zeroed[j]) || p.accumulate) ? 2 : 6;
             while (sk * 2 <= want && per_wave / (sk * 2) * 2 >= min_steps) sk *= 2;
         }
         if (force_sk > 0) sk = force_sk;
@@ -158,7 +175,7 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves 
         mp.item_end[j] = total;
     }
     mp.total_items = total;
-    grid = total < kNumCU ? total : kNumCU;
+    grid = total < cap ? total : cap;
 }
 
 // Geometry of one phase of a chain launch (tc_chain.h): 8 waves per workgroup, every workgroup owns at most ONE item
@@ -246,8 +263,10 @@ int dequant_chunks(int nrows, int st1, int st2) {
     return nch;
 }
 
+// An accumulating job (out += y: the residual add of a decoder block) is never zeroed: its split-K atomics add onto what
+// `out` already holds, which IS the accumulation (a memset here would silently turn h + y into y).
 int zero_if_split(const TcParams &p, int m, hipStream_t stream, int out_zeroed = 0) {
-    if (p.sk > 1 && !out_zeroed) {
+    if (p.sk > 1 && !out_zeroed && !p.accumulate) {
         for (int b = 0; b < p.n; b++) {
             hipError_t e = hipMemsetAsync(p.out + (long)b * p.ldo, 0, sizeof(float) * (size_t)m, stream);
             if (e != hipSuccess) return (int)e;

@@ -66,18 +66,28 @@ __device__ __forceinline__ void load_words_nt(const uint32_t *__restrict__ pg, u
 }
 
 // 32 bits of the lane's little-endian word array starting at compile-time bit POS (reads past the
-// end as zero: only ever the don't-care bits above a 16-bit window).
-template <int POS, int NW>
+// end as zero: only ever the don't-care bits above a 16-bit window).  WIDTH: how many of the low result bits the caller
+// looks at — when they all lie inside one dword the extract is a plain v_lshrrev_b32 (or nothing), which issues at full
+// rate on gfx950; v_alignbit_b32, like every three-operand integer op, at half rate (profiles/r02_valu_rate2.txt).
+template <int POS, int NW, int WIDTH = 32>
 __device__ __forceinline__ uint32_t ext32(const uint32_t (&w)[NW]) {
     static_assert(POS >= 0, "negative bit position");
     constexpr int i = POS >> 5, sh = POS & 31;
     const uint32_t lo = (i < NW) ? w[i < NW ? i : 0] : 0u;
     if constexpr (sh == 0) {
         return lo;
+#ifndef QPAL_NO_NARROW_EXT
+    } else if constexpr (sh + WIDTH <= 32) {
+        return lo >> sh;
+#endif
     } else {
         const uint32_t hi = (i + 1 < NW) ? w[(i + 1 < NW) ? i + 1 : 0] : 0u;
         return __builtin_amdgcn_alignbit(hi, lo, sh);
     }
+}
+template <int POS, int WIDTH, int NW>
+__device__ __forceinline__ uint32_t extw(const uint32_t (&w)[NW]) {
+    return ext32<POS, NW, WIDTH>(w);
 }
 
 // value of lane+1 inside each row of 16 lanes (wraps 15 -> 0): one DPP move, no LDS traffic.

@@ -107,7 +107,14 @@ struct TcqCodec {
     // then ONE v_and_or_b32: (h & mask) | 4*(lane mod copies).  Lanes l and l+16 of a 32-lane ds_read_b32
     // group share a copy, so half of the gathers are 2-way bank conflicts: LDS has the slack, the
     // half-rate VALU does not (perf/valu_rate.hip).
-    static constexpr int ROWSHIFT = 15 - S;            // log2(bytes per entry row)
+    // Experiment (make VARIANT=cf EXTRA=-DQPAL_CONFLICT_FREE, S = 9 only): 32 copies per entry (128 KiB, one bank per lane of a
+    // ds_read_b32 group: no conflicts) addressed through 2h = h + h — a fourth VALU op per pair, full rate.  DESIGN.md §4.9.
+#ifdef QPAL_CONFLICT_FREE
+    static constexpr int XS = S == 9 ? 1 : 0;
+#else
+    static constexpr int XS = 0;
+#endif
+    static constexpr int ROWSHIFT = 15 - S + XS;       // log2(bytes per entry row)
     static constexpr int LOG2C = ROWSHIFT - 2;         // copies per entry
     static constexpr int C = 1 << LOG2C;
     static constexpr int LDS_DWORDS = (1 << (S + 1)) * C;  // 16384
@@ -149,6 +156,17 @@ struct TcqCodec {
         }
     }
 
+    // States that reach into the next reference lane's bits (KV > 4: those with I*KV + 16 > L4) are cut from ONE joined word
+    // per chunk: z = [top NMAX bits of the next chunk | low 32-NMAX bits of this chunk], NMAX = 16 - KV = what the LAST state
+    // needs from its successor.  The last state is z itself, state I is z >> (3-I)*KV: one half-rate v_alignbit per chunk and
+    // full-rate shifts, instead of one v_alignbit per state.
+    static constexpr int NMAX = 16 - KV;
+    template <int G, bool ISB>
+    static __device__ __forceinline__ uint32_t joined_next(const uint32_t (&w)[NW], uint32_t next_head) {
+        if constexpr (!ISB) return __builtin_amdgcn_alignbit(extw<baseA<G>(), 32 - NMAX>(w), ext32<baseB<G>() + L4 - 32>(w), 32 - NMAX);
+        else return __builtin_amdgcn_alignbit(extw<baseB<G>(), 32 - NMAX>(w), next_head, 32 - NMAX);
+    }
+
     // trellis state in the LOW 16 bits, garbage above
     template <int G, int I>
     static __device__ __forceinline__ uint32_t window(const uint32_t (&w)[NW], uint32_t next_head) {
@@ -157,21 +175,24 @@ struct TcqCodec {
             const uint32_t y = joined<G>(w);
             if constexpr (n <= 0) return y >> (-n);
             else return __builtin_amdgcn_alignbit(y, next_head, 32 - n);
-        } else if constexpr (I < 4) {
-            constexpr int t0 = I * KV;
-            if constexpr (t0 + 16 <= L4) {
-                return ext32<baseA<G>() + L4 - 16 - t0>(w);
-            } else {
-                constexpr int n = t0 + 16 - L4;
-                return __builtin_amdgcn_alignbit(ext32<baseA<G>()>(w), ext32<baseB<G>() + L4 - 32>(w), 32 - n);
-            }
         } else {
-            constexpr int t0 = (I - 4) * KV;
+            constexpr bool ISB = I >= 4;
+            constexpr int t0 = (I & 3) * KV;
+            constexpr int base = ISB ? baseB<G>() : baseA<G>();
             if constexpr (t0 + 16 <= L4) {
-                return ext32<baseB<G>() + L4 - 16 - t0>(w);
+                return extw<base + L4 - 16 - t0, 16>(w);
             } else {
+#ifdef QPAL_NO_NARROW_EXT
                 constexpr int n = t0 + 16 - L4;
-                return __builtin_amdgcn_alignbit(ext32<baseB<G>()>(w), next_head, 32 - n);
+                if constexpr (!ISB) return __builtin_amdgcn_alignbit(ext32<baseA<G>()>(w), ext32<baseB<G>() + L4 - 32>(w), 32 - n);
+                else return __builtin_amdgcn_alignbit(ext32<baseB<G>()>(w), next_head, 32 - n);
+#else
+                const uint32_t z = joined_next<G, ISB>(w, next_head);  // (CSE: one per chunk)
+                constexpr int sh = (3 - (I & 3)) * KV;
+                static_assert(sh + 16 <= 32, "state window inside the joined word");
+                if constexpr (sh == 0) return z;
+                else return z >> sh;
+#endif
             }
         }
     }
@@ -183,6 +204,7 @@ struct TcqCodec {
         const uint32_t s = window<G, I>(w, next_head);
         uint32_t h;
         asm("v_mad_u32_u24 %0, %1, %1, %1" : "=v"(h) : "v"(s));  // s*s + s: low 16 bits exact
+        if constexpr (XS == 1) asm("v_add_u32 %0, %1, %1" : "=v"(h) : "v"(h));  // (h << 1 as a shift is a half-rate op)
         const uint32_t a = (h & HMASK) | laneoff;
         return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + a);
     }
@@ -265,7 +287,14 @@ struct StreamView {
 #define QPAL_STAMP(i) do { } while (0)
 #endif
 
+// Experiment (make VARIANT=w8 EXTRA=-DQPAL_W8): TWO 8-wave workgroups per CU instead of one 16-wave one for the
+// batch <= 16 kernels — 64 KiB image + 15 KiB scratch each (x fits only for n * k <= ~7000: the k = 4096 launches at batch 1),
+// 128 VGPRs as before (4 waves per SIMD).  No fused rotation in this build.
+#ifdef QPAL_W8
+constexpr int kScratchBytes = 15 * 1024;
+#else
 constexpr int kScratchBytes = 31 * 1024;  // LDS left beside the 128 KiB codebook image: reduction buffer + x
+#endif
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
@@ -287,6 +316,26 @@ struct Acc {
     float4_t v[NBG][4];
 };
 
+// Layout of the staged activations (batch <= 8, XLDS): inside every block of 32 halves (one supertile column) the eight
+// 4-half pieces p0..p7 are stored as [p0 p2 p4 p6 | p1 p3 p5 p7] — the lane of column half u reads 16 contiguous halves at
+// 16 u.  xs_put stores the 16-byte chunk of halves [i, i + 8) (i a multiple of 8); xs_index maps one half.
+__device__ __forceinline__ void xs_put(uint16_t *xs, int i, u32x4 v) {
+#ifdef QPAL_XPERM
+    uint16_t *d = xs + (i & ~31) + ((i >> 3) & 3) * 4;
+    *reinterpret_cast<u32x2 *>(d) = u32x2{v.x, v.y};
+    *reinterpret_cast<u32x2 *>(d + 16) = u32x2{v.z, v.w};
+#else
+    *reinterpret_cast<u32x4 *>(xs + i) = v;
+#endif
+}
+__device__ __forceinline__ int xs_index(int i) {
+#ifdef QPAL_XPERM
+    return (i & ~31) | (((i >> 2) & 1) << 4) | (((i >> 3) & 3) << 2) | (i & 3);
+#else
+    return i;
+#endif
+}
+
 // MFMA B operand of a step.  Lane (kb = lane>>4, c = lane&15) supplies, for batch row b = 8*grp + (c>>1) and
 // column half u = c&1, the 8 activations  x[b][col0 + 32*sc + 16*ksub + 8*jh + 4*u + 0..3], jh = 0,1
 // (order matches the A fragment: jh-major, then the reference lanes A|B, then the element of the pair).
@@ -305,6 +354,13 @@ __device__ __forceinline__ void load_step_x(const StreamView &sv, const uint16_t
         b = b < n ? b : n - 1;
         const int off = b * k + sv.col0 + sc * 32 + 4 * (c & 1);
         if constexpr (XLDS) {
+#ifdef QPAL_XPERM
+            // staged x is PERMUTED inside every 32-half block (xs_put below): the four 8-byte pieces a lane needs are
+            // contiguous, so the B operand of a step is two ds_read_b128 (4 LDS cycles each) instead of two ds_read2_b64 (8)
+            const uint16_t *row = xs + (live ? off + 12 * (c & 1) : zero_off);
+            xb[grp][0] = *reinterpret_cast<const u32x4 *>(row);
+            xb[grp][1] = *reinterpret_cast<const u32x4 *>(row + 8);
+#else
             const uint16_t *row = xs + (live ? off : zero_off);
 #pragma unroll
             for (int ksub = 0; ksub < 2; ksub++) {
@@ -312,6 +368,7 @@ __device__ __forceinline__ void load_step_x(const StreamView &sv, const uint16_t
                 const u32x2 hi = *reinterpret_cast<const u32x2 *>(row + 16 * ksub + 8);
                 xb[grp][ksub] = u32x4{lo.x, lo.y, hi.x, hi.y};
             }
+#endif
         } else {
             const uint16_t *row = xg + (live ? off : 0);
 #pragma unroll
@@ -356,6 +413,9 @@ __device__ __forceinline__ void gemv_step(const uint32_t *lut, uint32_t laneoff,
 
 // steps [s0, s1) of one stream; `w` already holds step s0 (loaded before the codebook image was built).
 // Two register sets ping-pong (loop unrolled by 2) so the one-step-ahead prefetch costs no copies.
+// (Round 3, measured: deeper prefetch — two or three steps in flight, whole rounds of 3 / 4 steps without a branch so that the
+// compiler's vmcnt bookkeeping stays exact — is 10-19 % SLOWER on every launch kind: profiles/r03_ab_ring.txt, DESIGN.md §4.9.
+// The steps phase is bound by the LDS gathers and the VALU together, not by load latency.)
 template <class Codec, bool XLDS, int NBG>
 __device__ __forceinline__ void gemv_run(uint32_t (&w)[Codec::NW], const uint32_t *lut, uint32_t laneoff,
                                          const StreamView &sv, const uint16_t *xg, const uint16_t *xs, int k, int n,
@@ -383,11 +443,22 @@ __device__ __forceinline__ void gemv_run(uint32_t (&w)[Codec::NW], const uint32_
 
 // Waves per workgroup of the fused kernel: 16 (4 per SIMD, 128 VGPRs) up to batch 16; 8 (2 per SIMD, 256 VGPRs: room for
 // the accumulators and activations of 4 / 8 batch groups) for batches 17..64, where every decoded step feeds 32 / 64 MFMAs
+#ifdef QPAL_W8
+template <int NBG>
+constexpr int gemv_waves() { return 8; }
+#define QPAL_GEMV_BOUNDS(NBG) __launch_bounds__(512, (NBG) <= 2 ? 4 : 2)
+#else
 template <int NBG>
 constexpr int gemv_waves() { return NBG >= 4 ? 8 : 16; }
+#define QPAL_GEMV_BOUNDS(NBG) __launch_bounds__(64 * gemv_waves<NBG>())
+#endif
 // LDS beside the 64 KiB codebook image: reduction buffer [waves][n][32] fp32 (+ x for batch <= 8)
 template <int NBG>
+#ifdef QPAL_CONFLICT_FREE  // (experiment build: batch 1 only — the wide-batch kernels compile but must not be launched)
+constexpr int scratch_bytes() { return kScratchBytes; }
+#else
 constexpr int scratch_bytes() { return NBG == 1 ? kScratchBytes : gemv_waves<NBG>() * 32 * 4 * 8 * NBG; }
+#endif
 
 // Mixed-precision launches: everything about a TCQ codec except the bit surgery depends on the codebook size S only (the
 // LDS image, its address mask, the hash), so single-stream layers of one S but DIFFERENT KV — q, k and v of a mixed-scheme
@@ -450,6 +521,11 @@ __device__ __forceinline__ void dispatch_lut(int bits, int vec, F &&f) {
 // The leading scalar arguments are PRELOADED into SGPRs by the dispatcher (-mllvm -amdgpu-kernarg-preload-count, Makefile):
 // when every job of the launch reads the same activations and codebook (`early`), their loads are issued before the
 // kernel-argument block `mp` has even arrived (its fetch is a memory round trip on the critical path of a short kernel).
+#ifdef QPAL_W8
+constexpr int kEarlyXChunks = 1;
+#else
+constexpr int kEarlyXChunks = 2;
+#endif
 struct TcEarly {
     const uint16_t *x;  // shared by all jobs, staged in LDS
     const void *tab;    // shared codebook
@@ -460,7 +536,8 @@ struct TcEarly {
 // host: the launch qualifies when x is staged in LDS and every job has the same x, codebook and batch
 inline TcEarly early_args(const TcMultiParams &mp) {
     const TcParams &a = mp.job[0];
-    TcEarly e{a.x, a.tab, a.n, a.k, a.x_lds && !a.x_rot && a.n <= 8 ? 1 : 0};
+    // (x and its 32-half zero pad must fit the chunks the threads hold: 16 384 halves per 16-wave workgroup)
+    TcEarly e{a.x, a.tab, a.n, a.k, a.x_lds && !a.x_rot && a.n <= 8 && a.n * a.k + 32 <= kEarlyXChunks * 64 * gemv_waves<1>() * 8 ? 1 : 0};
     for (int j = 1; j < mp.njobs; j++) {
         const TcParams &b = mp.job[j];
         if (b.x != a.x || b.tab != a.tab || b.n != a.n || b.k != a.k || !b.x_lds || b.x_rot) e.on = 0;
@@ -469,7 +546,7 @@ inline TcEarly early_args(const TcMultiParams &mp) {
 }
 
 template <class C1, class C2, int NBG, bool ROT = false>
-__global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const uint16_t *ex, const void *etab, int en, int ek, int eon,
+__global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const void *etab, int en, int ek, int eon,
                                                        const TcMultiParams mp) {
     constexpr bool TWO = !std::is_void_v<C2>;
     using CB = std::conditional_t<TWO, C2, C1>;
@@ -491,24 +568,30 @@ __global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const u
     int cur_j = 0;
     // early staging, part 1: request x and the codebook entries from the preloaded arguments (held in registers until
     // the first weight loads have been issued)
-    constexpr int NV = (C1::CHUNKS + 1023) / 1024;
+    constexpr int NV = (C1::CHUNKS + NT - 1) / NT;
     // (the 128 KiB images of the wide VQ/SQ codebooks would hold 8 entries per thread: spills, measured 20-30 % slower)
-    constexpr bool kEarly = NBG == 1 && !ROT && NV <= 4;
-    [[maybe_unused]] u32x4 exr[2];
-    [[maybe_unused]] uint32_t etv[NV];
+#ifdef QPAL_CONFLICT_FREE
+    constexpr bool kEarly = NBG == 1 && !ROT;
+#else
+    constexpr bool kEarly = NBG == 1 && !ROT && NV * NT <= 4096;  // <= 4 entries per thread of a 16-wave workgroup
+#endif
+    constexpr int EV = NV < 4 ? NV : 4;  // image entries a thread holds across the argument fetch; the rest are built after it
+    constexpr int XR = kEarlyXChunks;    // 16-byte chunks of x a thread holds likewise
+    [[maybe_unused]] u32x4 exr[XR];
+    [[maybe_unused]] uint32_t etv[EV];
     const bool early = kEarly && eon != 0;
     if constexpr (kEarly) {
         if (early) {
             const int total = en * ek;
 #pragma unroll
-            for (int r = 0; r < 2; r++) {
-                const int i = tid * 8 + r * 8192;
+            for (int r = 0; r < XR; r++) {
+                const int i = tid * 8 + r * (NT * 8);
                 exr[r] = u32x4{0u, 0u, 0u, 0u};
                 if (i < total) exr[r] = *reinterpret_cast<const u32x4 *>(ex + i);
             }
 #pragma unroll
-            for (int r = 0; r < NV; r++) {
-                const int c = tid + r * 1024;
+            for (int r = 0; r < EV; r++) {
+                const int c = tid + r * NT;
                 etv[r] = C1::entry(etab, ((c < C1::CHUNKS ? c : 0) * 4) >> C1::LOG2C);
             }
         }
@@ -609,14 +692,20 @@ __global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const u
             if (early && gitem == (int)blockIdx.x) {  // early staging, part 2: registers -> LDS
                 const int total = en * ek;
 #pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    const int i = tid * 8 + r * 8192;
-                    if (i < total + 32) *reinterpret_cast<u32x4 *>(xs + i) = exr[r];
+                for (int r = 0; r < XR; r++) {
+                    const int i = tid * 8 + r * (NT * 8);
+                    if (i < total + 32) xs_put(xs, i, exr[r]);
                 }
 #pragma unroll
-                for (int r = 0; r < NV; r++) {
-                    const int c = tid + r * 1024;
+                for (int r = 0; r < EV; r++) {
+                    const int c = tid + r * NT;
                     if (c < C1::CHUNKS) reinterpret_cast<u32x4 *>(lut)[c] = u32x4{etv[r], etv[r], etv[r], etv[r]};
+                }
+                if constexpr (EV < NV) {  // (8-wave experiment build only)
+                    for (int c = tid + EV * NT; c < C1::CHUNKS; c += NT) {
+                        const uint32_t v = C1::entry(etab, (c * 4) >> C1::LOG2C);
+                        reinterpret_cast<u32x4 *>(lut)[c] = u32x4{v, v, v, v};
+                    }
                 }
                 cur_x = ex;
                 cur_tab = etab;
@@ -700,7 +789,7 @@ __global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const u
                     }
                     auto store_row = [&](uint16_t *dst) {
                         return [=](int, int, int i, float v) {
-                            dst[i] = __builtin_bit_cast(uint16_t, (_Float16)((float)(_Float16)(v * post) * p.x_post));
+                            dst[xs_index(i)] = __builtin_bit_cast(uint16_t, (_Float16)((float)(_Float16)(v * post) * p.x_post));
                         };
                     };
                     if (p.x_rot == 4) wht64_wg_stage2<4>(wave, lane, p.x_pre, d1buf, store_row(xs));
@@ -710,7 +799,7 @@ __global__ __launch_bounds__(64 * gemv_waves<NBG>()) void tc_gemv_kernel(const u
                     for (int i = tid * 8; i < total + 32; i += NT * 8) {
                         u32x4 v{0u, 0u, 0u, 0u};
                         if (i < total) v = *reinterpret_cast<const u32x4 *>(p.x + i);
-                        *reinterpret_cast<u32x4 *>(xs + i) = v;
+                        xs_put(xs, i, v);
                     }
                 }
                 cur_x = p.x;

@@ -27,12 +27,12 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
         hipMalloc(&d, nb);
         hipMemset(d, 0, nb);
         q.dbg = d;
-        for (int rep = 0; rep < 3; rep++) { TcMultiParams mq = mp; mq.job[0] = q; hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(1024), 0, stream, e.x, e.tab, e.n, e.k, e.on, mq); }
+        for (int rep = 0; rep < 3; rep++) { TcMultiParams mq = mp; mq.job[0] = q; hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, mq); }
         hipDeviceSynchronize();
         unsigned long long *h = (unsigned long long *)malloc(nb);
         hipMemcpy(h, d, nb, hipMemcpyDeviceToHost);
         // s_memrealtime: 100 MHz, one clock for the whole device (10 ns steps) — spans across workgroups are meaningful
-        unsigned long long t0 = ~0ull, t7 = 0;
+        unsigned long long t0 = ~0ull, t7 = 0, t0max = 0, t7min = ~0ull;
         double ph[8] = {0}, phmax[8] = {0};
         int nw = 0;
         for (int w = 0; w < grid * 16; w++) {
@@ -40,6 +40,8 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
             nw++;
             if (h[w * 8] < t0) t0 = h[w * 8];
             if (h[w * 8 + 7] > t7) t7 = h[w * 8 + 7];
+            if (h[w * 8] > t0max) t0max = h[w * 8];
+            if (h[w * 8 + 7] < t7min) t7min = h[w * 8 + 7];
             unsigned long long prev = h[w * 8];
             for (int i = 1; i < 8; i++) {  // a stamp the path did not pass (early staging skips 2 and 3) reads 0: zero-length phase
                 const unsigned long long cur = h[w * 8 + i] ? h[w * 8 + i] : prev;
@@ -49,8 +51,8 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
                 prev = cur;
             }
         }
-        printf("[stamps] %s grid %d m %d k %d wpr %d sk %d: first stamp -> last stamp %.2f us; mean / max per-wave phase (us):", ROT ? "ROT" : "plain", grid,
-               p.nrows * 32, p.k, 1 << p.log2_wpr, p.sk, (t7 - t0) / 100.0);
+        printf("[stamps] %s grid %d m %d k %d wpr %d sk %d: first stamp -> last stamp %.2f us (wave starts spread over %.2f us, wave ends over %.2f us); mean / max per-wave phase (us):", ROT ? "ROT" : "plain", grid,
+               p.nrows * 32, p.k, 1 << p.log2_wpr, p.sk, (t7 - t0) / 100.0, (t0max - t0) / 100.0, (t7 - t7min) / 100.0);
         const char *nm[8] = {"", "issue-w", "x+lut", "barrier", "steps", "xor-red", "barrier2", "final"};
         for (int i = 1; i < 8; i++) printf(" %s %.2f/%.2f", nm[i], ph[i] / (nw ? nw : 1) / 100.0, phmax[i] / 100.0);
         printf("\n");

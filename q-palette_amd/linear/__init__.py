@@ -181,7 +181,7 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
     x_rot = (su, post_scale): x is the UN-rotated input and every launch stages fp16(fp16(H (x*su)/sqrt(k)) * post)
     itself (only where rotation_fusable(layers, n)); x may then be the fp32 residual stream, and x_rms = (eps, weight or
     None) applies the RMSNorm in front of the rotation (decoder-block fusion).  accumulate: outs[i] += y_i (the residual add:
-    outs[i] holds the residual stream; with outs_zeroed=True the launch may split K and add with atomics).
+    outs[i] holds the residual stream; the launch may split K on its own: the atomics add onto the live output, outs_zeroed is ignored).
     act_out (fp16 [1, m / 2]; one layer built by interleave_up_gate, batch 1, x_rot): the launch's epilogue writes
     silu(gate) * up there and no fp32 output (returns [None])."""
     from .. import ops

@@ -176,10 +176,36 @@ def test_rmsnorm_fp32_stream_and_accumulate_in_the_gemv_launch(qp, qstr):
     tol = 2.0 ** -9 * float(ref.abs().max())  # rsqrt / summation-order differences move a few inputs by one fp16 ulp
     assert torch.allclose(got, ref, atol=tol, rtol=2e-3), float((got - ref).abs().max())
     acc = torch.full((1, m), 0.5, device=dev)
-    qp.multi_gemv([layer], h32, outs=[acc], outs_zeroed=True, wscales=[wsc], oscale=scale, x_rot=(su, 1.0 / scale),
+    qp.multi_gemv([layer], h32, outs=[acc], wscales=[wsc], oscale=scale, x_rot=(su, 1.0 / scale),
                   x_rms=(eps, w_ln), accumulate=True)
     torch.cuda.synchronize()
     assert torch.allclose(acc, got + 0.5, atol=tol, rtol=2e-3)
+
+
+@pytest.mark.parametrize("qstr", ["tcomb_6_7_0.5_none_0.9", "tcq_6_none_0.9", "ldlq_2_8_none_1.0"])
+@pytest.mark.parametrize("n", [1, 3])
+def test_accumulate_into_a_live_buffer_under_split_k(qp, qstr, n):
+    """accumulate=True with the truthful outs_zeroed=False on a few-rows x long-K layer (Llama-8B down_proj: the launch planner
+    splits K over workgroups there): out must end up as h + y.  A memset in front of the split-K atomics would leave y alone
+    (qpal_capi.hip zero_if_split)."""
+    dev = torch.device("cuda", 0)
+    k, m = 14336, 4096
+    layer = qp.make_linear_from_info(qstr, qp.mem_op.dummy_linear_info(k, m, qstr, seed=5)).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(n, k, device=dev, generator=gen).half()
+    (y,) = qp.multi_gemv([layer], x)
+    h = torch.randn(n, m, device=dev, generator=gen) * 100.0
+    acc = h.clone()
+    qp.multi_gemv([layer], x, outs=[acc], accumulate=True)
+    torch.cuda.synchronize()
+    assert float((acc - h).abs().max()) > 1.0, "nothing was added"
+    tol = 1e-5 * float(y.abs().max()) * 64 + 2.0 ** -17 * 400.0   # fp32 order of summation + the fp32 add onto |h| <= ~400
+    assert torch.allclose(acc, h + y, atol=tol, rtol=1e-5), float((acc - (h + y)).abs().max())
+    # and the flag the harness used to pass by mistake changes nothing
+    acc2 = h.clone()
+    qp.multi_gemv([layer], x, outs=[acc2], outs_zeroed=True, accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.allclose(acc2, h + y, atol=tol, rtol=1e-5)
 
 
 @pytest.mark.parametrize("n", [8192, 5120, 4096, 2048, 11008])
