@@ -92,7 +92,35 @@ def parse_args():
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: put every rank on this GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-whole-model", action="store_true",
+                    help="skip the `whole_model_decode` figure of the default N = 1 run (the fused decode step of perf/decode_llama.py)")
+    ap.add_argument("--no-tp-leg", action="store_true",
+                    help="N > 1: skip the `tp_70b` figures (Llama-3.1-70B shapes row-sharded over the N GPUs, batch 1 and 16)")
+    ap.add_argument("--tp-layers", type=int, default=0, help="layers of the tp_70b leg (0 = the model's 80)")
+    ap.add_argument("--tp-steps", type=int, default=0, help="timed steps of each tp_70b figure (0 = min(--steps, 30))")
     return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher: start the N ranks as child processes (one per GPU, the same command line,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) BEFORE anything in this process touches the GPU, wait for
+    them and pass rank 0's output (the ONE JSON line) through.  Nothing is re-exec'ed: the parent stays a plain Python process."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p_ in procs:
+        rc = max(rc, abs(p_.wait()))
+    return rc
 
 
 _KIND = {"self_attn.q_proj": "q", "self_attn.k_proj": "k", "self_attn.v_proj": "v", "self_attn.o_proj": "o",
@@ -292,7 +320,7 @@ def algorithmic_bytes(qp, layers, batch):
     return total
 
 
-def cpu_baseline(qp, layers, batch, seconds):
+def cpu_baseline(qp, layers, batch, seconds, nl=None):
     """CPU baseline (kind "port": the oracle's restatement of what the reference does without a GPU — fake-dequant to fp16 W,
     then fp32-accumulate x @ W.T; lib/quantizer/quant_op.py:185-201, lib/utils/kernel_decompress.py:64-88) on ONE layer's
     linears of the same workload: all host cores (OpenMP) and one thread, W materialised and fused (decode a tile, multiply,
@@ -328,7 +356,7 @@ def cpu_baseline(qp, layers, batch, seconds):
             ts.append(time.perf_counter() - t0)
         return float(np.median(ts)), len(ts)
 
-    nl = len(layers)
+    nl = nl or len(layers)
     ncores = oracle.num_threads()
     variants = {}
     run_one(host[0], False)  # warm-up: page faults, table init
@@ -362,6 +390,8 @@ def cpu_baseline(qp, layers, batch, seconds):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     import torch
     import torch.distributed as dist
 
@@ -642,12 +672,137 @@ def main():
                                         "to fp16 W in HBM (staged 16-byte stores) + fp16 GEMM (hipBLASLt)"}
     if extra is not None:
         out["with_incoherence_wrapper"] = extra
+    if isinstance(gather, qp.shard.PeerGatherer):
+        assert gather.error() == 0, "a peer gather gave up waiting for a flag: the figures above are invalid"
+        out["config"]["peer_gather"] = {"flag_memory": gather.flag_memory, "world": world}
+    if os.environ.get("QPAL_BENCH_SHARED_WEIGHTS"):
+        # experiment knob (cache-resident weights): NOT the benchmark — say so where the number is read
+        out["config"]["INVALID_experiment_knob"] = "QPAL_BENCH_SHARED_WEIGHTS: every layer aliases layer 0's buffers"
+        out["metric"] = "EXPERIMENT (shared weights), not the headline metric"
+    if world > 1 and not args.no_tp_leg and not tp:
+        # BASELINE configs[4]: Llama-3.1-70B shapes @3.0 b row-sharded over the N GPUs, batch 1 and batch 16 (strong scaling),
+        # after the headline's timed region; every rank takes part (collectives), rank 0 reports
+        try:
+            out["tp_70b"] = tp_leg(qp, torch, dist, args, rank, world, device)
+        except Exception as exc:  # the headline line must not depend on this leg
+            out["tp_70b"] = {"error": repr(exc)}
     if rank == 0:
+        if world == 1 and not args.no_whole_model and not args.incoherent and n == 1:
+            # the reference's own metric (eval/measure_latency.py:236-272 times whole-model generate()): the fused decode step of
+            # perf/decode_llama.py — embedding, 32 decoder blocks (6 launches each), final norm + lm_head + argmax — short context
+            try:
+                out["whole_model_decode"] = whole_model_leg(args)
+            except Exception as exc:
+                out["whole_model_decode"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(qp, layers, n, args.cpu_seconds)
+            layers = build_model(qp, torch, model_key, qstr, 1, device, distinct_codebooks=args.distinct_codebooks,
+                                 packing=args.packing, keep_infos=True)
+            out["cpu_baseline"] = cpu_baseline(qp, layers, n, args.cpu_seconds, nlayers)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def whole_model_leg(args):
+    """tokens/s of a whole Llama-3.1-8B-shaped greedy decode step on this library's fused decoder-block glue (the same quantizer
+    as the headline workload where it is a single scheme; the published fusion-aware qdict otherwise), KV cache of 1024 positions."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_qpal_decode_llama", os.path.join(ROOT, "perf", "decode_llama.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    model_key, qstr = WORKLOADS[args.workload]
+    argv = ["--model", model_key, "--no-modular", "--tokens", str(max(16, min(args.steps, 64))), "--context", "1024"]
+    argv += ["--qdict", qstr[6:]] if qstr.startswith("qdict:") else ["--quantizer", qstr]
+    if args.layers:
+        argv += ["--layers", str(args.layers)]
+    r = mod.main(argv, quiet=True)
+    return {"value": 1e3 / r["ms_fused_glue"], "unit": "tokens/s", "ms_per_step": r["ms_fused_glue"],
+            "launches_per_token": r["launches_per_token"], "context": 1024,
+            "what": "whole-model greedy decode step, batch 1: embedding + every decoder block on the fused glue (RMSNorm + rotation "
+                    "inside the q|k|v and up|gate launches, rope + cache append + attention as one launch, residual adds inside "
+                    "o / down) + final norm, fp16 lm_head and argmax as one launch; HIP-graph replay; "
+                    "the reference times the same thing as generate() (eval/measure_latency.py:236-272)"}
+
+
+def tp_leg(qp, torch, dist, args, rank, world, device):
+    """Llama-3.1-70B-shaped token (uniform tcq_6 = 3.0 b/w, BASELINE configs[4]) with every linear row-sharded over the `world`
+    ranks: multi-job launches on each rank's shard, the outputs of o_proj / down_proj all-gathered.  Figures at
+    batch 1 and batch 16, each with the one-shot peer-write gather inside a HIP graph — but only after PeerGatherer.validate()
+    has agreed with the library collective on this node — and with dist.all_gather_into_tensor (RCCL) between eager launches
+    as the checked baseline.  value = the faster VALID one."""
+    model_key, qstr = WORKLOADS["llama3.1-70b_tcq_6"]
+    nl = args.tp_layers or qp.mem_op.get_layer_info(model_key)["nlayers"]
+    steps = args.tp_steps or max(5, min(args.steps, 30))
+    layers = build_model(qp, torch, model_key, qstr, nl, device, shard=(rank, world))
+    hidden = max(m.out_features for groups in layers for grp in (groups[1], groups[3]) for m, _, _ in grp) * world
+    res = {"workload": f"llama3.1-70b_tcq_6: {nl} layers, row-sharded over {world} ranks ({qstr})", "world": world,
+           "backend": args.dist_backend}
+    peer = None
+    try:
+        peer = qp.shard.PeerGatherer(world, rank, device, max_bytes=16 * hidden * 4 // world + 4096, slots=2 * nl + 2)
+        res["peer_gather"] = {"flag_memory": peer.flag_memory, "validated_against_collective": bool(peer.validate())}
+    except Exception as exc:
+        res["peer_gather"] = {"error": repr(exc), "validated_against_collective": False}
+    stream = torch.cuda.Stream(device)
+
+    def timed(token, graphable):
+        with torch.cuda.stream(stream):
+            token()
+            torch.cuda.synchronize()
+            run = token
+            if graphable:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    token()
+                run = g.replay
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                run()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t[0]) / steps
+
+    for nb in (1, 16):
+        xs = {}
+        for groups in layers:
+            for mod, k, _ in (u for grp in groups for u in grp):
+                if k not in xs:
+                    xs[k] = torch.randn(nb, k, device=device).half()
+        abytes = algorithmic_bytes(qp, layers, nb)  # per rank
+        fig = {}
+        if peer is not None and res["peer_gather"].get("validated_against_collective"):
+            token, _ = make_token(qp, torch, layers, xs, nb, device, launch="multi", gather=peer)
+            t = timed(token, True)
+            torch.cuda.synchronize()
+            if peer.error() == 0:
+                fig["peer_gather_in_graph"] = {"tokens_per_s": nb / t, "ms_per_step": t * 1e3}
+            else:
+                fig["peer_gather_in_graph"] = {"error": "a peer gather gave up waiting for a flag"}
+                res["peer_gather"]["validated_against_collective"] = False
+        coll = qp.shard.make_gatherer(world, device)
+        token, _ = make_token(qp, torch, layers, xs, nb, device, launch="multi", gather=coll)
+        t = timed(token, False)
+        fig["collective_eager"] = {"tokens_per_s": nb / t, "ms_per_step": t * 1e3}
+        valid = [v for v in fig.values() if "tokens_per_s" in v]
+        best = max(valid, key=lambda v: v["tokens_per_s"])
+        fig["value"] = best["tokens_per_s"]
+        fig["unit"] = "tokens/s"
+        fig["ms_per_step"] = best["ms_per_step"]
+        fig["roofline_frac_per_gpu"] = abytes / (best["ms_per_step"] / 1e3) / 1e9 / HBM_PEAK_GBS
+        res[f"bs{nb}"] = fig
+    if peer is not None:
+        peer.close()
+    return res
 
 
 def load_traffic(workload):

@@ -252,6 +252,19 @@ int qpal_pack_lut_simt(void *dst, const int32_t *idx, int m, int k, int bits, in
 #define QPAL_PEER_WS_BYTES_PER_SLOT 256
 int qpal_peer_gather(const void *src, long bytes, int slot, void *const *peer_bufs, void *const *peer_ws, int rank,
                      int world, void *stream);
+/* Set-up helpers of the peer gather (the ONLY entry points of this library that allocate; not on the data path).  The flag
+ * blocks are written by a remote GPU while a kernel of this GPU spins on them, so they must not live in ordinary (coarse-
+ * grained) device memory, which is only guaranteed coherent at kernel boundaries: qpal_peer_alloc returns `bytes` bytes of
+ * zero-filled device memory on the current device — kind 1: fine-grained (hipDeviceMallocFinegrained), 2: uncached
+ * (hipDeviceMallocUncached), 0: plain hipMalloc (the gather buffers themselves: their contents are consumed after the
+ * kernel boundary).  qpal_ipc_export writes the 64-byte IPC handle of an allocation; qpal_ipc_open maps another process's
+ * allocation into this one (peer access enabled lazily); qpal_ipc_close / qpal_peer_free undo them.                      */
+#define QPAL_IPC_HANDLE_BYTES 64
+int qpal_peer_alloc(void **ptr, long bytes, int kind);
+int qpal_peer_free(void *ptr);
+int qpal_ipc_export(void *ptr, void *handle64);
+int qpal_ipc_open(const void *handle64, void **ptr);
+int qpal_ipc_close(void *ptr);
 
 /* Decoder-block glue of a batch-1 decode step, one launch: rotary embedding of the new token's q and k (HF rotate_half
  * convention, cos / sin of pos * inv_freq rounded to fp16, fp16 arithmetic: model/llama.py apply_rotary_pos_emb), q as fp16,

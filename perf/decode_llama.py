@@ -95,7 +95,7 @@ class DecoderLayer(nn.Module):
         return h + self.mlp(self.post_attention_layernorm(h))
 
 
-def main(argv=None):
+def main(argv=None, quiet=False):
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="3_8b", choices=sorted(qp.mem_op.LAYER_INFO))
     ap.add_argument("--quantizer", default="tcomb_6_7_0.5_none_0.9")
@@ -332,9 +332,13 @@ def main(argv=None):
         if not fusable:
             raise SystemExit("--no-modular: this configuration has no fused-glue step")
         t_fused = timed_fused()
-        print(json.dumps({"model": args.model, "layers": nlayers, "quantizer": args.qdict or args.quantizer, "context": args.context,
-                          "tokens_per_s_fused_glue": 1.0 / t_fused, "ms_fused_glue": t_fused * 1e3}))
-        return {"ms_whole_step": None, "ms_fused_glue": t_fused * 1e3, "check": None}
+        # kernel launches of one fused step: per layer q|k|v (+ its rotation where the GEMV cannot rotate), attention, o (+ rotation),
+        # up|gate (+ rotation), SwiGLU rotation, down; + the norm / lm_head / argmax launch (the embedding row copy is a memcpy node)
+        per_layer = 6 if rot_in_gemv else 9
+        if not quiet:
+            print(json.dumps({"model": args.model, "layers": nlayers, "quantizer": args.qdict or args.quantizer, "context": args.context,
+                              "tokens_per_s_fused_glue": 1.0 / t_fused, "ms_fused_glue": t_fused * 1e3}))
+        return {"ms_whole_step": None, "ms_fused_glue": t_fused * 1e3, "check": None, "launches_per_token": per_layer * nlayers + 1}
     t_full = timed(True)
     t_proj = timed(False)
     t_fused = timed_fused() if fusable else None

@@ -40,6 +40,7 @@ class ChainPhase(ctypes.Structure):
 
 CHAIN_WS_BYTES = 2048
 PEER_WS_BYTES_PER_SLOT = 256
+IPC_HANDLE_BYTES = 64
 
 
 _SIGNATURES = {
@@ -71,6 +72,11 @@ _SIGNATURES = {
     "qpal_lm_head_argmax": [_P, _P, _F, _P, _P, _P, _P, ctypes.c_long, _I, _I, _P],
     "qpal_lm_head_ws_bytes": [_I],
     "qpal_peer_gather": [_P, ctypes.c_long, _I, ctypes.POINTER(_P), ctypes.POINTER(_P), _I, _I, _P],
+    "qpal_peer_alloc": [ctypes.POINTER(_P), ctypes.c_long, _I],
+    "qpal_peer_free": [_P],
+    "qpal_ipc_export": [_P, ctypes.c_char_p],
+    "qpal_ipc_open": [ctypes.c_char_p, ctypes.POINTER(_P)],
+    "qpal_ipc_close": [_P],
 }
 
 

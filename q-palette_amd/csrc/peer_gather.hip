@@ -11,6 +11,7 @@
 //   wait until the LOCAL flag[slot][p] >= e      (system-scope atomic loads, bounded spin)
 // When the kernel has ended, every slice has arrived; the kernel boundary makes the peers' writes visible to what follows.
 #include <hip/hip_runtime.h>
+#include <string.h>
 
 #include "qpal_common.h"
 
@@ -80,3 +81,43 @@ extern "C" int qpal_peer_gather(const void *src, long bytes, int slot, void *con
     hipLaunchKernelGGL(peer_gather_kernel, dim3(world), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return (int)hipGetLastError();
 }
+
+// ---- set-up helpers (include/qpal.h): fine-grained / uncached flag memory and IPC mapping ------------------------------
+extern "C" int qpal_peer_alloc(void **ptr, long bytes, int kind) {
+    if (!ptr) return QPAL_E_NULL;
+    if (bytes <= 0 || kind < 0 || kind > 2) return QPAL_E_PARAM;
+    void *p = nullptr;
+    hipError_t e = kind == 0 ? hipMalloc(&p, (size_t)bytes)
+                             : hipExtMallocWithFlags(&p, (size_t)bytes, kind == 1 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemset(p, 0, (size_t)bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return (int)e;
+    }
+    *ptr = p;
+    return QPAL_OK;
+}
+
+extern "C" int qpal_peer_free(void *ptr) { return ptr ? (int)hipFree(ptr) : QPAL_OK; }
+
+static_assert(sizeof(hipIpcMemHandle_t) == QPAL_IPC_HANDLE_BYTES, "IPC handle size");
+
+extern "C" int qpal_ipc_export(void *ptr, void *handle64) {
+    if (!ptr || !handle64) return QPAL_E_NULL;
+    hipIpcMemHandle_t h;
+    hipError_t e = hipIpcGetMemHandle(&h, ptr);
+    if (e != hipSuccess) return (int)e;
+    memcpy(handle64, &h, sizeof(h));
+    return QPAL_OK;
+}
+
+extern "C" int qpal_ipc_open(const void *handle64, void **ptr) {
+    if (!handle64 || !ptr) return QPAL_E_NULL;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof(h));
+    return (int)hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess);
+}
+
+extern "C" int qpal_ipc_close(void *ptr) { return ptr ? (int)hipIpcCloseMemHandle(ptr) : QPAL_OK; }

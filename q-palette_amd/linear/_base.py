@@ -1,17 +1,17 @@
-"""Shared plumbing of the quantized linears: batch dispatch (fused GEMV for bs <= 8, dequant + fp16
-GEMM above) and the row-concatenating ``merge_infos`` used for QKV / up+gate layer fusion."""
+"""Shared plumbing of the quantized linears: batch dispatch (fused decode + GEMV / skinny GEMM up to ``max_fused_batch``,
+decode-to-fp16 + fp16 GEMM above) and the row-concatenating ``merge_infos`` used for QKV / up+gate layer fusion."""
 import torch
 import torch.nn as nn
 
 from .. import ops
 
-GEMV_MAX_BATCH = 8  # reference: `if bs <= 8` in every forward (e.g. lib/linear/tcq_linear.py:68)
+GEMV_MAX_BATCH = 8  # reference: `if bs <= 8` in every forward (e.g. lib/linear/tcq_linear.py:68); SIMT packings keep it
 
 
 class PackedLinearBase(nn.Module):
     in_features: int
     out_features: int
-    max_fused_batch = GEMV_MAX_BATCH  # tensor-core-order families raise this to 16 (second MFMA column group)
+    max_fused_batch = GEMV_MAX_BATCH  # tensor-core-order families raise this to 64 (8 MFMA column groups; 32 under a 128 KiB image)
 
     def _gemv(self, x, bs):  # -> [bs, m] (fp32 or fp16)
         raise NotImplementedError

@@ -108,41 +108,92 @@ class PeerGatherer:
     the captured graph, no library collective.  Every rank allocates `slots` gather buffers and one flag block and opens
     every peer's through IPC handles exchanged with torch.distributed (any backend: the data path never touches it again).
 
-    Call sites: each call inside a token takes the next slot (buffers and flags are never shared between call sites, so a fast
-    rank cannot overwrite what a slow peer still reads); call `new_token()` before re-running or capturing a token so that
-    the same call sites map to the same slots.  RCCL's all_gather (`make_gatherer`) stays the correctness baseline."""
+    Memory: the flag blocks are polled by a running kernel while a REMOTE GPU writes them, so they live in fine-grained
+    device memory (qpal_peer_alloc kind 1; uncached as second choice) — ordinary hipMalloc memory is only guaranteed coherent
+    at kernel boundaries.  `flag_memory` says which kind was obtained ("fine-grained" / "uncached" / "coarse-grained": the
+    last only if the platform refused both, and then `validated` matters all the more).  The gather buffers are consumed
+    after the gather kernel has ended (kernel boundary), so they stay ordinary memory.
+
+    Call sites: each call inside a token takes the next slot (buffers and flags are never shared between call sites).  A fast
+    rank can start token T+1 while a slow peer still runs token T, but it cannot pass the token's LAST call site before that
+    peer has launched its own last call — which is stream-ordered behind the peer's consumers of every EARLIER site.  So the
+    view returned for call site s may be overwritten only once its consumers are done, PROVIDED s is not the only site:
+    a token needs >= 2 call sites (checked by new_token()); with a single site per token use two gatherers alternately.
+    Call `new_token()` before re-running or capturing a token so that the same call sites map to the same slots.
+    RCCL's all_gather (`make_gatherer`) stays the correctness baseline: `validate()` compares the two on this node."""
 
     def __init__(self, world, rank, device, max_bytes, slots=64, group=None):
+        import ctypes
         from . import _native as nat
         self.nat = nat
         self.world, self.rank, self.device = world, rank, torch.device(device)
         self.max_bytes = (max_bytes + 15) // 16 * 16
         self.slots = slots
         self._next = 0
+        self._sites_last_token = None
         self._group = group
         self._widths = {}  # call site -> per-rank slice widths (exchanged once, during the first, un-captured token)
-        self.bufs = torch.zeros(slots * world * self.max_bytes, dtype=torch.uint8, device=self.device)
-        self.ws = torch.zeros(slots * nat.PEER_WS_BYTES_PER_SLOT, dtype=torch.uint8, device=self.device)
-        torch.cuda.synchronize(self.device)
-        mine = (self.bufs.untyped_storage()._share_cuda_(), self.bufs.storage_offset(),
-                self.ws.untyped_storage()._share_cuda_(), self.ws.storage_offset())
+        self.validated = None
+        lib = nat.lib()
+        nbuf = slots * world * self.max_bytes
+        nws = slots * nat.PEER_WS_BYTES_PER_SLOT
+        self._own, self._opened = [], []
+
+        def alloc(nbytes, kinds):
+            with torch.cuda.device(self.device):
+                for kind in kinds:
+                    ptr = ctypes.c_void_p()
+                    if lib.qpal_peer_alloc(ctypes.byref(ptr), nbytes, kind) == 0:
+                        h = ctypes.create_string_buffer(nat.IPC_HANDLE_BYTES)
+                        if lib.qpal_ipc_export(ptr, h) == 0:
+                            self._own.append(ptr.value)
+                            return ptr.value, h.raw, kind
+                        lib.qpal_peer_free(ptr)
+            raise nat.QpalError("PeerGatherer: no shareable device memory (qpal_peer_alloc / qpal_ipc_export failed)")
+
+        self._bufs_ptr, hb, _ = alloc(nbuf, (0,))
+        self._ws_ptr, hw, kind = alloc(nws, (1, 2, 0))
+        self.flag_memory = {1: "fine-grained", 2: "uncached", 0: "coarse-grained"}[kind]
         everyone = [None] * world
-        dist.all_gather_object(everyone, mine, group=group)
-        self._peer_storages = []
+        dist.all_gather_object(everyone, (hb, hw), group=group)
         self.peer_bufs, self.peer_ws = [], []
-        for r, (hb, ob, hw, ow) in enumerate(everyone):
-            if r == rank:
-                self.peer_bufs.append(self.bufs.data_ptr())
-                self.peer_ws.append(self.ws.data_ptr())
-                continue
-            sb = torch.UntypedStorage._new_shared_cuda(*hb)
-            sw = torch.UntypedStorage._new_shared_cuda(*hw)
-            self._peer_storages += [sb, sw]
-            self.peer_bufs.append(sb.data_ptr() + ob)
-            self.peer_ws.append(sw.data_ptr() + ow)
+        with torch.cuda.device(self.device):
+            for r, (pb, pw) in enumerate(everyone):
+                if r == rank:
+                    self.peer_bufs.append(self._bufs_ptr)
+                    self.peer_ws.append(self._ws_ptr)
+                    continue
+                ptrs = []
+                for h in (pb, pw):
+                    ptr = ctypes.c_void_p()
+                    nat.check(lib.qpal_ipc_open(h, ctypes.byref(ptr)), "qpal_ipc_open")
+                    self._opened.append(ptr.value)
+                    ptrs.append(ptr.value)
+                self.peer_bufs.append(ptrs[0])
+                self.peer_ws.append(ptrs[1])
+        # torch views of this rank's own allocations (results are views into bufs; error() reads ws)
+        self.bufs = _tensor_from_ptr(self._bufs_ptr, nbuf, self.device, self)
+        self.ws = _tensor_from_ptr(self._ws_ptr, nws, self.device, self)
         dist.barrier(group=group)
 
+    def close(self):
+        """Unmap the peers' allocations and free this rank's (after a barrier: nobody may still be writing here)."""
+        lib = self.nat.lib()
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            for p in self._opened:
+                lib.qpal_ipc_close(p)
+            self._opened = []
+            dist.barrier(group=self._group)
+            for p in self._own:
+                lib.qpal_peer_free(p)
+            self._own = []
+
     def new_token(self):
+        if self._next == 1 and self._sites_last_token == 1:
+            raise RuntimeError("PeerGatherer: a token with ONE call site may overwrite a slice a slow peer still reads; use >= 2 "
+                               "call sites per token (or two gatherers alternately)")
+        self._sites_last_token = self._next if self._next else self._sites_last_token
         self._next = 0
 
     def __call__(self, y):
@@ -160,6 +211,7 @@ class PeerGatherer:
         widths = self._widths[slot]
         # every rank writes at rank * seg inside the slot's buffer; seg = the widest slice, so equal widths land contiguously
         seg = max(widths) * n * y.element_size()
+        assert seg % 16 == 0 and seg <= self.max_bytes, "padded slice: 16-byte multiple that fits the slot"
         base = slot * self.world * self.max_bytes
         arr_b = (ctypes.c_void_p * self.world)(*[b + base for b in self.peer_bufs])
         arr_w = (ctypes.c_void_p * self.world)(*self.peer_ws)
@@ -183,3 +235,68 @@ class PeerGatherer:
         """!= 0 after a synchronisation: a wait for a peer's flag gave up."""
         return int(self.ws.view(torch.int32).view(self.slots, -1)[:, 32].abs().sum().item())
 
+    def validate(self, n=1, width=2048, rounds=8, dtype=torch.float32):
+        """Compare the peer gather with the library collective (dist.all_gather_into_tensor: RCCL on a real node) on THIS node's
+        links: `rounds` tokens of two call sites each, eager and from a replayed HIP graph, every word checked, plus the
+        bounded-wait error word.  Uses (and then releases) the first two slots.  -> True / False, the same on every rank."""
+        assert self.slots >= 2 and n * width * torch.empty((), dtype=dtype).element_size() <= self.max_bytes
+        dev = self.device
+        saved = (self._next, self._sites_last_token, dict(self._widths))
+        self._widths = {}  # the validation's own slice widths for the two slots it borrows
+        srcs = [torch.empty(n, width, dtype=dtype, device=dev) for _ in range(2)]
+        ok = True
+
+        def fill(step):
+            for i, s_ in enumerate(srcs):
+                s_.copy_((torch.arange(n * width, device=dev, dtype=torch.float32).view(n, width) * 0.5
+                          + 1000.0 * self.rank + 10000.0 * i + 100000.0 * step).to(dtype))
+
+        def reference():
+            outs = []
+            for s_ in srcs:
+                buf = torch.empty((self.world * n, width), dtype=dtype, device=dev)
+                dist.all_gather_into_tensor(buf, s_.contiguous(), group=self._group)
+                outs.append(buf.view(self.world, n, width).permute(1, 0, 2).reshape(n, self.world * width))
+            return outs
+
+        def token():
+            self.new_token()
+            return [self(s_).clone() for s_ in srcs]
+
+        stream = torch.cuda.Stream(dev)
+        with torch.cuda.stream(stream):
+            for step in range(rounds // 2):
+                fill(step)
+                torch.cuda.synchronize(dev)
+                got = token()
+                torch.cuda.synchronize(dev)
+                ok = ok and all(torch.equal(g, r) for g, r in zip(got, reference()))
+            dist.barrier(group=self._group)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                got = token()
+            for step in range(rounds // 2, rounds):
+                fill(step)
+                torch.cuda.synchronize(dev)
+                graph.replay()
+                torch.cuda.synchronize(dev)
+                ok = ok and all(torch.equal(g, r) for g, r in zip(got, reference()))
+        ok = ok and self.error() == 0
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, int(flag.item()), group=self._group)
+        self._next, self._sites_last_token, self._widths = saved[0], saved[1], saved[2]
+        self.validated = all(gathered)
+        return self.validated
+
+
+def _tensor_from_ptr(ptr, nbytes, device, owner):
+    """uint8 torch view of a raw device allocation (kept alive by `owner`)."""
+    class _Mem:
+        pass
+    m = _Mem()
+    m.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+    m._owner = owner
+    t = torch.as_tensor(m, device=device)
+    t._qpal_owner = m
+    return t

@@ -39,3 +39,63 @@ def test_bench_prints_one_contract_line(monkeypatch):
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     w = d["with_incoherence_wrapper"]
     assert "error" not in w and 0 < w["value"] < d["value"]
+    wm = d["whole_model_decode"]  # the reference's own metric (whole-model decode step), measured after the headline
+    assert "error" not in wm and wm["unit"] == "tokens/s" and 0 < wm["value"] < d["value"] and wm["launches_per_token"] == 2 * 6 + 1
+
+
+def test_gpus_n_without_a_launcher_spawns_the_ranks(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` with WORLD_SIZE unset (how the driver calls it) must start its N ranks itself, as child
+    processes, before anything touches a GPU.  CPU check of exactly that code path: the children are this test's stand-in
+    script (bench.spawn_ranks starts `sys.executable <bench.__file__> <argv>`), which records the environment it was given."""
+    sys.path.insert(0, ROOT)
+    import bench
+    probe = tmp_path / "probe.py"
+    probe.write_text(
+        "import json, os, sys\n"
+        "out = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'rank%s.json' % os.environ['RANK'])\n"
+        "json.dump({k: os.environ.get(k) for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', "
+        "'HSA_ENABLE_IPC_MODE_LEGACY')} | {'argv': sys.argv[1:]}, open(out, 'w'))\n"
+        "print('{\"rank\": %s}' % os.environ['RANK'])\n"
+        "sys.exit(3 if os.environ['RANK'] == '1' and '--fail' in sys.argv else 0)\n")
+    monkeypatch.setattr(bench, "__file__", str(probe))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3", "--steps", "2"])
+    for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.spawn_ranks(3) == 0
+    got = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(3)]
+    assert [g["RANK"] for g in got] == ["0", "1", "2"] and [g["LOCAL_RANK"] for g in got] == ["0", "1", "2"]
+    assert all(g["WORLD_SIZE"] == "3" and g["MASTER_ADDR"] == "127.0.0.1" and g["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for g in got)
+    assert len({g["MASTER_PORT"] for g in got}) == 1 and all(g["argv"] == ["--gpus", "3", "--steps", "2"] for g in got)
+    # a failing rank fails the whole run
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--fail"])
+    assert bench.spawn_ranks(2) == 3
+    # and main() takes that path only when no launcher set WORLD_SIZE
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert exc.value.code == 0
+
+
+@pytest.mark.gpu
+def test_gpus_2_rehearsed_on_one_gpu_through_the_spawn_path():
+    """`python bench.py --gpus 2 --force-device 0 --dist-backend gloo` — no launcher — on the one-GPU box: the parent spawns two
+    ranks that share the card, rank 0 prints ONE line: dp replicas as the headline and the tp_70b leg (row-sharded 70B shapes,
+    batch 1 and 16, peer gather validated against the collective, then timed inside a HIP graph)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--force-device", "0", "--dist-backend", "gloo",
+           "--steps", "4", "--warmup", "1", "--layers", "2", "--tp-layers", "2", "--no-kind-breakdown"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "dp2" in d["config"]["parallelism"]
+    tp = d["tp_70b"]
+    assert "error" not in tp and tp["world"] == 2
+    assert tp["peer_gather"]["validated_against_collective"] is True and tp["peer_gather"]["flag_memory"] in ("fine-grained", "uncached", "coarse-grained")
+    for key in ("bs1", "bs16"):
+        fig = tp[key]
+        assert fig["value"] > 0 and "tokens_per_s" in fig["collective_eager"] and "tokens_per_s" in fig["peer_gather_in_graph"]

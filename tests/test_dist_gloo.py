@@ -195,8 +195,12 @@ def _peer_worker(rank, world, port, ret):
                 torch.cuda.synchronize()
                 ok = ok and all(torch.equal(o.cpu(), expect(i, step)) for i, o in enumerate(outs))
         ok = ok and g.error() == 0
+        ok = ok and g.flag_memory in ("fine-grained", "uncached", "coarse-grained")
+        ok = ok and g.validate(n=2, width=1024)   # against the collective (gloo here, RCCL on a real node), eager + graph replay
+        ok = ok and g.error() == 0
         dist.barrier()
-        ret.put((rank, bool(ok)))
+        g.close()
+        ret.put((rank, bool(ok), g.flag_memory))
     finally:
         dist.destroy_process_group()
 
@@ -217,3 +221,4 @@ def test_peer_gather_two_ranks_on_one_gpu():
         assert p.exitcode == 0
     got = sorted(ret.get(timeout=5) for _ in range(world))
     assert [g[1] for g in got] == [True] * world, got
+    print("peer gather flag memory:", got[0][2])

@@ -203,8 +203,10 @@ def test_llama_shapes_modules(qp, oracle, qstr, k, m):
         y = layer(x.cuda().float())  # fp32 in -> fp32 out keeps the kernel's fp32 result
         assert y.dtype == torch.float32 and tuple(y.shape) == (n, m)
         _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle)
-    # bs > 8: decode + fp16 GEMM path (what the perplexity eval exercises)
-    x = torch.randn(16, k, generator=gen).half()
+    # bs > max_fused_batch (64): the module's decode-to-fp16 + fp16 GEMM path — what the perplexity eval exercises
+    # (eval_qdict.py:17-38 at bs = 8192; lib/linear/tcq_linear.py:75-84); tighter check: test_module_path_above_the_fused_batch
+    x = torch.randn(80, k, generator=gen).half()
+    assert x.shape[0] > layer.max_fused_batch
     y = layer(x.cuda()).float().cpu().numpy()
     ref = (x.float() @ torch.from_numpy(W).float().T).numpy()
     assert np.allclose(y, ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max())
@@ -606,3 +608,54 @@ def test_comb_layer_row_shards(qp, oracle):
         y = torch.cat(parts, dim=1)
         ref = full(x)
         assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max())), world
+
+
+@pytest.mark.parametrize("qstr,k,m,n", [("tcomb_6_7_0.5_none_0.9", 4096, 4096, 128), ("tcq_6_none_0.9", 14336, 4096, 128),
+                                        ("ldlq_2_12_none_1.0", 4096, 1024, 48), ("ldlq_1_4_none_1.0", 4096, 2048, 128),
+                                        ("tcomb_6_7_0.5_none_0.9", 4096, 14336, 1024)])
+def test_module_path_above_the_fused_batch(qp, oracle, qstr, k, m, n):
+    """The path the perplexity eval takes (bs = 8192 there: eval_qdict.py:17-38): above max_fused_batch the module decodes W to
+    fp16 (bit-exact, checked elsewhere) and multiplies with the fp16 GEMM, as the reference does for bs > 8
+    (lib/linear/tcq_linear.py:75-84).  Against the oracle's fp64 GEMM on the oracle's W: fp32 accumulation + ONE fp16 rounding
+    of the output."""
+    info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=11)
+    layer = qp.make_linear_from_info(qstr, info).cuda()
+    assert n > layer.max_fused_batch
+    W = _oracle_weight(oracle, qstr, info, m, k)
+    x = torch.randn(n, k, generator=torch.Generator().manual_seed(n)).half()
+    y = layer(x.cuda())
+    assert y.dtype == torch.float16 and tuple(y.shape) == (n, m)
+    rows = np.arange(0, n, max(1, n // 16))  # the oracle's float64 GEMV on 16 batch rows spread over the batch
+    _check_gemv(y[rows].float().cpu().numpy(), W, x[rows].numpy(), oracle, fp16_out=True)
+
+
+L70 = {"qkv": (8192, 10240), "o": (8192, 8192), "ug": (8192, 57344), "d": (28672, 8192)}
+
+
+@pytest.mark.parametrize("kind", sorted(L70))
+@pytest.mark.parametrize("rank", [0, 5])
+def test_llama70b_row_shard_of_8(qp, oracle, kind, rank):
+    """BASELINE configs[4] in its sharded form: rank r of 8 of the Llama-3.1-70B q|k|v, o, gate|up and down layers (tcq_6,
+    3.0 b/w; shard_linear_info: rows of W in units of one supertile row — /root/reference/lib/utils/mem_op.py:65-95 for the
+    shapes) through the HIP path at batch 1 and batch 16, against the oracle on that shard."""
+    qstr = "tcq_6_none_0.9"
+    k, m = L70[kind]
+    full = qp.mem_op.dummy_linear_info(k, m, qstr, seed=70 + len(kind), device="cpu")
+    info = qp.shard.shard_linear_info(full, rank, 8)
+    r0, r1 = qp.shard.shard_bounds(m, 8, rank)
+    ms = r1 - r0
+    assert info["out_features"] == ms == m // 8
+    per_row16 = k // 16
+    assert torch.equal(info["trellis"], full["trellis"][r0 // 16 * per_row16: r1 // 16 * per_row16])
+    layer = qp.make_linear_from_info(qstr, info).cuda()
+    W = _oracle_weight(oracle, qstr, info, ms, k)
+    if kind == "o":  # and the shard IS rows [r0, r1) of the unsharded layer's weight
+        Wf = _oracle_weight(oracle, qstr, full, m, k)
+        assert np.array_equal(Wf[r0:r1].view(np.uint16), W.view(np.uint16))
+    assert np.array_equal(_bits(layer.get_weight()), W.view(np.uint16))
+    gen = torch.Generator().manual_seed(rank)
+    for n in (1, 16):
+        x = torch.randn(n, k, generator=gen).half()
+        (y,) = qp.multi_gemv([layer], x.cuda())
+        assert y.dtype == torch.float32 and tuple(y.shape) == (n, ms)
+        _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle)
