@@ -261,7 +261,7 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
                     # beyond the fused batch: decode to fp16 W (staged 16-byte stores) + fp16 GEMM, as the reference does for
                     # bs > 8 (lib/linear/tcq_linear.py:75-84); the MFMA roofline of this path is reported by --batch
                     if only_kind is None or only_kind == gi:
-                        outs += [m(x) for m in mods]
+                        outs += qp.multi_gemv(mods, x)   # passes of the fused launches up to max_chunked_batch, decode + GEMM above
                     continue
                 if launch in ("multi", "chain") and gather is None:
                     # projections of one input: one multi-job launch per codec.  The attention-input / mlp-input

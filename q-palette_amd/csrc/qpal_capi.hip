@@ -7,6 +7,7 @@
 #include "lut_kernels_api.h"
 #include "tcq_kernels_api.h"
 #include "chain_api.h"
+#include "tc_gemm.h"
 #include <string.h>
 
 using namespace qpal;
@@ -178,6 +179,47 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves 
     grid = total < cap ? total : cap;
 }
 
+// Geometry of the lockstep skinny-GEMM kernel (tc_gemm.h, batch > 8): a workgroup = 8 waves = 8 supertile rows that walk one K
+// range together; K is split over workgroups (float atomics into a zeroed output) only while the launch has too few row groups
+// to occupy the chip and every split keeps >= kGemmMinSteps steps.  QPAL_GEMM_SK=<n> forces the split (experiments).
+constexpr int kGemmMinSteps = 4;
+void plan_gemm(TcMultiParams &mp, int &grid) {
+    static const int force_sk = env_int("QPAL_GEMM_SK", 0);
+    static const int want_items = env_int("QPAL_GEMM_ITEMS", 192);  // measured: 96 / 192 / 256 / 512 -> 4.9 / 4.1 / 4.5 / 5.3 ms per Llama-8B step at batch 64
+    static const int min_steps = env_int("QPAL_GEMM_MINSTEPS", kGemmMinSteps);
+    int groups = 0;
+    for (int j = 0; j < mp.njobs; j++) groups += (mp.job[j].nrows + kGemmWaves - 1) / kGemmWaves;
+    int total = 0;
+    for (int j = 0; j < kMaxJobs; j++) {
+        if (j < mp.njobs) {
+            TcParams &p = mp.job[j];
+            const int T = p.st1 + p.st2;
+            int sk = 1;
+            while (groups * sk < want_items && T / (sk * 2) >= min_steps && sk < 32) sk *= 2;
+            if (force_sk > 0) sk = force_sk;
+            if (sk > T) sk = T;
+            p.sk = sk;
+            p.nitems = ((p.nrows + kGemmWaves - 1) / kGemmWaves) * sk;
+            total += p.nitems;
+        }
+        mp.item_end[j] = total;
+    }
+    mp.total_items = total;
+    grid = total < kNumCU ? total : kNumCU;
+}
+
+// batches 9..64: which kernel.  QPAL_GEMM=0: the per-wave-K-chunk kernel (tc_gemv_kernel, x from L2 per wave);
+// 1 (default): the lockstep kernel with the step's activations shared through LDS (tc_gemm.h)
+bool use_gemm(int nbg, const TcMultiParams &mp) {
+    static const int on = env_int("QPAL_GEMM", 1);
+    if (!on || nbg < 2) return false;
+    for (int j = 0; j < mp.njobs; j++) {
+        const TcParams &p = mp.job[j];
+        if (!aligned(p.x, 16) || (p.k % 8) || p.x_rot || p.act_out) return false;
+    }
+    return true;
+}
+
 // Geometry of one phase of a chain launch (tc_chain.h): 8 waves per workgroup, every workgroup owns at most ONE item
 // (grid = ncu workgroups, all resident).  Split-K only into outputs the caller guarantees zeroed (an earlier phase's
 // prezero): a chain cannot insert a memset between its phases.  false: the phase does not fit one round.
@@ -267,12 +309,18 @@ int dequant_chunks(int nrows, int st1, int st2) {
 // `out` already holds, which IS the accumulation (a memset here would silently turn h + y into y).
 int zero_if_split(const TcParams &p, int m, hipStream_t stream, int out_zeroed = 0) {
     if (p.sk > 1 && !out_zeroed && !p.accumulate) {
-        for (int b = 0; b < p.n; b++) {
-            hipError_t e = hipMemsetAsync(p.out + (long)b * p.ldo, 0, sizeof(float) * (size_t)m, stream);
-            if (e != hipSuccess) return (int)e;
-        }
+        // ONE node for the whole [n][m] block (a batch of 64 used to cost 64 memset nodes per layer)
+        hipError_t e = p.ldo == m ? hipMemsetAsync(p.out, 0, sizeof(float) * (size_t)m * p.n, stream)
+                                  : hipMemset2DAsync(p.out, sizeof(float) * (size_t)p.ldo, 0, sizeof(float) * (size_t)m, (size_t)p.n, stream);
+        if (e != hipSuccess) return (int)e;
     }
     return 0;
+}
+
+int launch_tcq_gemm(const TcMultiParams &mp, int S, int KV1, int KV2, int nbg, int grid, hipStream_t stream) {
+    return nbg == 2 ? launch_tcq_gemm_nbg2(mp, S, KV1, KV2, grid, stream)
+         : nbg == 4 ? launch_tcq_gemm_nbg4(mp, S, KV1, KV2, grid, stream)
+                    : launch_tcq_gemm_nbg8(mp, S, KV1, KV2, grid, stream);
 }
 
 int tcq_gemv_one(float *out, long ldo, const void *c1, const void *c2, const void *x, const void *tlut, int m, int n,
@@ -282,6 +330,12 @@ int tcq_gemv_one(float *out, long ldo, const void *c1, const void *c2, const voi
     tcq_fill(mp.job[0], out, ldo, c1, c2, x, tlut, m, n, k, k1, k2);
     int grid;
     const int nbg = nbg_of(n);
+    if (use_gemm(nbg, mp)) {
+        plan_gemm(mp, grid);
+        int rc = zero_if_split(mp.job[0], m, stream);
+        if (rc) return rc;
+        return launch_tcq_gemm(mp, S, KV1, KV2, nbg, grid, stream);
+    }
     plan_launch(mp, nullptr, grid, waves_of(nbg));
     int rc = zero_if_split(mp.job[0], m, stream);
     if (rc) return rc;
@@ -385,7 +439,9 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
     if (nbg >= 4)
         for (int j = 0; j < njobs; j++)
             if (jobs[j].x_had) return QPAL_E_SHAPE;  // fused rotation: batch 1
-    plan_launch(mp, zeroed, grid, waves_of(nbg));
+    const bool gemm = !mixed && use_gemm(nbg, mp);
+    if (gemm) plan_gemm(mp, grid);
+    else plan_launch(mp, zeroed, grid, waves_of(nbg));
     for (int j = 0; j < njobs; j++) {
         if (mp.job[j].act_out) {  // the SwiGLU epilogue pairs two supertile rows of one workgroup and has no split-K form
             if (mp.job[j].sk != 1 || (waves_of(nbg) >> mp.job[j].log2_wpr) < 2) return QPAL_E_SHAPE;
@@ -394,6 +450,7 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         int rc = zero_if_split(mp.job[j], jobs[j].m, s, jobs[j].out_zeroed);
         if (rc) return rc;
     }
+    if (gemm) return launch_tcq_gemm(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, nbg, grid, s);
     if (mixed) return launch_tcq_gemv_any(mp, S, grid, s);
     return launch_tcq_gemv(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, nbg, grid, s);
 }
@@ -501,7 +558,9 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
     const int nbg = nbg_of(n);
     // the reduction buffer of 8 batch groups (64 KiB) does not fit beside a 128 KiB codebook image
     if (nbg == 8 && lut_image_bytes(bits, vec) > 64 * 1024) return QPAL_E_SHAPE;
-    plan_launch(mp, zeroed, grid, waves_of(nbg));
+    const bool gemm = use_gemm(nbg, mp);
+    if (gemm) plan_gemm(mp, grid);
+    else plan_launch(mp, zeroed, grid, waves_of(nbg));
     for (int j = 0; j < njobs; j++) {
         if (mp.job[j].act_out) {
             if (mp.job[j].sk != 1 || (waves_of(nbg) >> mp.job[j].log2_wpr) < 2) return QPAL_E_SHAPE;
@@ -510,6 +569,7 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
         int rc = zero_if_split(mp.job[j], jobs[j].m, s, jobs[j].out_zeroed);
         if (rc) return rc;
     }
+    if (gemm) return launch_lut_tc_gemm(mp, bits, vec, nbg, grid, s);
     return launch_lut_tc_gemv(mp, bits, vec, nbg, grid, s);
 }
 

@@ -1,0 +1,236 @@
+// Fused decode + skinny GEMM for batches 9..64 (and, in passes of 64, beyond): out[n][m] = x[n][k] W^T with W decoded on the
+// fly, the activations of a step shared by the whole workgroup through LDS.
+//
+// Why a second kernel: tc_gemv_kernel's waves each own a K-chunk of a supertile row, so for a batch every wave fetches its own
+// [n][128] slice of x per step from L2 (16 KiB per wave-step at n = 64) and waits for it — at batch 64 the step was bound by
+// that round trip, not by the decode or the matrix pipe (7.7 ms per Llama-8B step: 0.05 of the MFMA roofline).  Here the 8
+// waves of a workgroup own 8 DIFFERENT supertile rows and walk the SAME K range in lockstep: the [n][128] tile of x of a step
+// is loaded ONCE per workgroup, one step ahead (global -> registers -> LDS, double-buffered, one barrier per step), in the
+// layout the MFMA B fragments are read in (one ds_read_b128 per batch group and ksub).  A wave sees its whole K range, so
+// there is no cross-wave reduction; split-K over workgroups (atomics) only where a layer has too few rows to fill the chip.
+//
+// Decode, MFMA mapping (virtual rows: tile row x column half), codecs and packed formats are tc_kernels.h's — same arithmetic
+// order per (row, batch) up to the K split.  Replaces, for bs > 8, the reference's decode-to-HBM + cuBLAS path
+// (lib/linear/tcq_linear.py:75-84, vq_linear.py:60-66) up to the batch where that path wins again.
+#pragma once
+#include "tc_kernels.h"
+
+namespace qpal {
+
+constexpr int kGemmWaves = 8;
+constexpr int kGemmXRow = 144;              // bytes per (batch row, column half) row of a step's x tile: 128 + 16 pad (bank spread)
+constexpr int kGemmXGroup = 16 * kGemmXRow;  // one batch group (8 rows x 2 column halves)
+
+// geometry of one job (host: plan_gemm): items = ceil(nrows / 8) * sk, item -> (row group, K split)
+//   uses TcParams: nrows, nsc1/2, st1/2, col2, sk, out/ldo, wscale/oscale, accumulate, c1/c2, x, tab, n, k
+
+template <class Codec, int NBG>
+__device__ __forceinline__ void gemm_step(const uint32_t *lut, uint32_t laneoff, const uint32_t (&w)[Codec::NW],
+                                          const unsigned char *xt, int lane, Acc<NBG> &acc) {
+    const unsigned char *xl = xt + (lane & 15) * kGemmXRow + (lane >> 4) * 32;
+    static_for<0, 2>([&](auto kc) {
+        constexpr int ksub = decltype(kc)::value;
+        __builtin_amdgcn_sched_barrier(0);  // one ksub's B fragments at a time (hoisting the second set spills at 8 batch groups)
+        u32x4 xb[NBG];
+        static_for<0, NBG>([&](auto bc) {
+            constexpr int grp = decltype(bc)::value;
+            xb[grp] = *reinterpret_cast<const u32x4 *>(xl + grp * kGemmXGroup + ksub * 16);
+        });
+        static_for<0, 2>([&](auto mc) {
+            constexpr int msub = decltype(mc)::value;
+            constexpr int g = ksub * 2 + msub;
+            uint32_t nh = 0u;
+            if constexpr (Codec::kNeedsNext) nh = row16_next(Codec::template head<g>(w));
+            static_for<0, 2>([&](auto jc) {
+                constexpr int jl = decltype(jc)::value;
+                const u32x4 a{Codec::template pair<g, jl>(lut, laneoff, w, nh), Codec::template pair<g, jl + 4>(lut, laneoff, w, nh),
+                              Codec::template pair<g, jl + 2>(lut, laneoff, w, nh), Codec::template pair<g, jl + 6>(lut, laneoff, w, nh)};
+                const half8_t afrag = __builtin_bit_cast(half8_t, a);
+                static_for<0, NBG>([&](auto bc) {
+                    constexpr int grp = decltype(bc)::value;
+                    acc.v[grp][msub * 2 + jl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                        afrag, __builtin_bit_cast(half8_t, xb[grp]), acc.v[grp][msub * 2 + jl], 0, 0, 0);
+                });
+            });
+        });
+    });
+}
+
+// which stream a global step of a row belongs to, and where its columns start
+struct GemmStep {
+    bool on2;
+    int s;         // step inside the stream
+    int col_base;  // first x column of the step
+    int col_end;   // end of the stream's live columns
+};
+__device__ __forceinline__ GemmStep gemm_where(const TcParams &p, int g) {
+    GemmStep r;
+    r.on2 = g >= p.st1;
+    r.s = r.on2 ? g - p.st1 : g;
+    r.col_base = (r.on2 ? p.col2 : 0) + r.s * 128;
+    r.col_end = r.on2 ? p.col2 + p.nsc2 * 32 : p.nsc1 * 32;
+    return r;
+}
+
+template <class C1, class C2, int NBG>
+__global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiParams mp) {
+    constexpr bool TWO = !std::is_void_v<C2>;
+    using CB = std::conditional_t<TWO, C2, C1>;
+    constexpr int W = kGemmWaves, NT = 64 * W;
+    constexpr int XBUF = NBG * kGemmXGroup;
+    constexpr int NCH = NBG * 8 * 16;                   // 16-byte chunks of one step's x tile
+    constexpr int CPT = (NCH + NT - 1) / NT;            // chunks per thread
+    constexpr int NWMAX = C1::NW > CB::NW ? C1::NW : CB::NW;
+    static_assert(2 * XBUF >= W * 1024, "the x buffers double as the epilogue's per-wave transposition scratch");
+    __shared__ __attribute__((aligned(16))) uint32_t lut[C1::LDS_DWORDS];
+    __shared__ __attribute__((aligned(16))) unsigned char xt[2 * XBUF];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t laneoff = (uint32_t)(lane & (C1::C - 1)) << 2;
+    const void *cur_tab = nullptr;
+    int ie[kMaxJobs];
+#pragma unroll
+    for (int i = 0; i < kMaxJobs; i++) ie[i] = mp.item_end[i];
+    const int total_items = ie[kMaxJobs - 1];
+    int cur_j = -1;
+    TcParams p;
+
+    for (int gitem = blockIdx.x; gitem < total_items; gitem += gridDim.x) {
+        int j = 0, item_begin = 0;
+#pragma unroll
+        for (int i = 0; i < kMaxJobs - 1; i++) {
+            if (gitem >= ie[i]) {
+                j = i + 1;
+                item_begin = ie[i];
+            }
+        }
+        if (j != cur_j) {
+            p = mp.job[j];
+            cur_j = j;
+        }
+        const int item = gitem - item_begin;
+        const int rg = item / p.sk, ks = item - rg * p.sk;
+        const int T = p.st1 + p.st2;
+        const int g0 = (int)((long)T * ks / p.sk), g1 = (int)((long)T * (ks + 1) / p.sk);
+        const int sr = rg * W + wave;
+        const bool live = sr < p.nrows;
+        const int srow = live ? sr : 0;
+        const StreamView sv1{p.c1 + (long)srow * p.nsc1 * 16 * C1::NW, p.nsc1, 0};
+        const StreamView sv2{TWO ? p.c2 + (long)srow * p.nsc2 * 16 * CB::NW : p.c1, TWO ? p.nsc2 : p.nsc1, p.col2};
+
+        uint32_t wcur[NWMAX], wnext[NWMAX];
+        u32x4 xr[CPT];
+        auto load_w = [&](int g, uint32_t(&dst)[NWMAX]) {
+            const GemmStep st = gemm_where(p, g);
+            if (TWO && st.on2) load_step_w<CB::NW>(sv2, st.s, lane, reinterpret_cast<uint32_t(&)[CB::NW]>(dst));
+            else load_step_w<C1::NW>(sv1, st.s, lane, reinterpret_cast<uint32_t(&)[C1::NW]>(dst));
+        };
+        // chunk id -> (batch row b = id >> 4, 16-byte piece q = id & 15 of the step's 128 columns)
+        auto load_x = [&](int g) {
+            const GemmStep st = gemm_where(p, g);
+#pragma unroll
+            for (int r = 0; r < CPT; r++) {
+                const int id = tid + r * NT;
+                const int b = id >> 4, col = st.col_base + 8 * (id & 15);
+                xr[r] = u32x4{0u, 0u, 0u, 0u};
+                if (id < NCH && b < p.n && col < st.col_end) xr[r] = *reinterpret_cast<const u32x4 *>(p.x + (long)b * p.k + col);
+            }
+        };
+        auto store_x = [&](unsigned char *buf) {
+#pragma unroll
+            for (int r = 0; r < CPT; r++) {
+                const int id = tid + r * NT;
+                if (id < NCH) {
+                    const int b = id >> 4, q = id & 15;
+                    // piece q = (supertile col sc = q >> 2, ksub = (q >> 1) & 1, jh = q & 1): halves 0..3 belong to column half u = 0, 4..7 to u = 1
+                    unsigned char *d = buf + (b >> 3) * kGemmXGroup + (2 * (b & 7)) * kGemmXRow + (q >> 2) * 32 + ((q >> 1) & 1) * 16 + (q & 1) * 8;
+                    *reinterpret_cast<u32x2 *>(d) = u32x2{xr[r].x, xr[r].y};
+                    *reinterpret_cast<u32x2 *>(d + kGemmXRow) = u32x2{xr[r].z, xr[r].w};
+                }
+            }
+        };
+
+        load_w(g0, wcur);
+        load_x(g0);
+        if (gitem == (int)blockIdx.x && mp.zero_chunks > 0) {  // pre-zero a buffer for a later split-K launch on this stream
+            for (int i = blockIdx.x * NT + tid; i < mp.zero_chunks; i += gridDim.x * NT) mp.zero[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+        if (p.tab != cur_tab) {  // workgroup-uniform
+            C1::build(lut, p.tab, tid, NT);
+            cur_tab = p.tab;
+        }
+        store_x(xt);
+        Acc<NBG> acc;
+        static_for<0, NBG>([&](auto bc) {
+            static_for<0, 4>([&](auto ac) { acc.v[decltype(bc)::value][decltype(ac)::value] = float4_t{0.f, 0.f, 0.f, 0.f}; });
+        });
+        __syncthreads();
+
+        // the steps of ONE stream (one codec: no branch inside the loop body); the prefetch of the step after the last one
+        // already belongs to the next stream (or re-requests the last step)
+        auto run = [&](auto codec_c, int ga, int gb) {
+            using CC = typename decltype(codec_c)::type;
+            for (int g = ga; g < gb; g++) {
+                const int gn = g + 1 < g1 ? g + 1 : g;
+                load_w(gn, wnext);
+                load_x(gn);
+                __builtin_amdgcn_sched_barrier(0);
+                const int par = (g - g0) & 1;
+                if (live)  // (wave-uniform: a row past the end of the layer only keeps the staging and the barriers company)
+                    gemm_step<CC, NBG>(lut, laneoff, reinterpret_cast<uint32_t(&)[CC::NW]>(wcur), xt + par * XBUF, lane, acc);
+                store_x(xt + (par ^ 1) * XBUF);  // last read before the previous barrier
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < NWMAX; i++) wcur[i] = wnext[i];
+            }
+        };
+        {
+            const int mid = g1 < p.st1 ? g1 : (g0 > p.st1 ? g0 : p.st1);
+            if (g0 < mid) run(std::type_identity<C1>{}, g0, mid);
+            if constexpr (TWO) {
+                if (mid < g1) run(std::type_identity<CB>{}, mid, g1);
+            }
+        }
+
+        // ---- epilogue: lane (q = lane >> 4, cidx = lane & 15 = 2 b' + u) holds, for batch row 8 grp + b' and a = msub * 2 + jl,
+        // D[4 q + r][cidx]; valid where (r & 1) == u: on even lanes own r = 0 / 2 plus the odd neighbour's r = 1 / 3 are tile rows
+        // 8 a + 2 q + {0, 1}.  One batch group at a time goes through a per-wave [8][32] fp32 scratch and leaves as 128-byte runs.
+        float *scr = reinterpret_cast<float *>(xt) + wave * 256;
+        const int q = lane >> 4, cidx = lane & 15;
+        const int r32 = lane & 31;
+        float osc = p.oscale;
+        if (p.wscale && live) osc *= (float)__builtin_bit_cast(_Float16, p.wscale[sr * 32 + r32]);
+        auto epilogue = [&](auto mode_c) {
+            constexpr int mode = decltype(mode_c)::value;  // 0: store, 1: out += (residual add), 2: split-K atomics
+            static_for<0, NBG>([&](auto bc) {
+                constexpr int grp = decltype(bc)::value;
+                static_for<0, 4>([&](auto ac) {
+                    constexpr int a = decltype(ac)::value;
+                    const float4_t d = acc.v[grp][a];
+                    const float v0 = d[0] + __shfl_xor(d[1], 1, 64);
+                    const float v1 = d[2] + __shfl_xor(d[3], 1, 64);
+                    if ((cidx & 1) == 0) *reinterpret_cast<float2 *>(scr + (cidx >> 1) * 32 + 8 * a + 2 * q) = float2{v0, v1};
+                });
+                // (wave-private scratch: LDS operations of one wave complete in order)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int bl = 2 * i + (lane >> 5), b = 8 * grp + bl;
+                    const float v = scr[bl * 32 + r32] * osc;
+                    if (live && b < p.n) {
+                        float *dst = p.out + (long)b * p.ldo + (long)sr * 32 + r32;
+                        if constexpr (mode == 2) atomicAdd(dst, v);
+                        else if constexpr (mode == 1) *dst += v;
+                        else *dst = v;
+                    }
+                }
+            });
+        };
+        if (p.sk > 1) epilogue(std::integral_constant<int, 2>{});
+        else if (p.accumulate) epilogue(std::integral_constant<int, 1>{});
+        else epilogue(std::integral_constant<int, 0>{});
+        __syncthreads();  // the scratch is the next item's x buffer
+    }
+}
+
+}  // namespace qpal

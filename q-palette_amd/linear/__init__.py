@@ -203,10 +203,21 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
         else:
             raise RuntimeError("multi_gemv: act_out needs a tensor-core-order packed layer")
         return [None]
-    if n > min(l.max_fused_batch for l in layers):  # decode-to-fp16 + GEMM path of the modules: the fused-launch extras have no meaning there
+    fused = min(l.max_fused_batch for l in layers)
+    if n > fused:
         if outs is not None or prezero is not None or wscales is not None or oscale != 1.0 or x_rot is not None or accumulate:
             raise RuntimeError("multi_gemv: outs / prezero / wscales / oscale / x_rot need a fused batch (n <= 64)")
-        return [l(x2) for l in layers]
+        if n <= min(l.max_chunked_batch for l in layers):
+            # passes of the fused launches over slices of the batch (each pass keeps the multi-job grouping): faster than
+            # decode-to-HBM + GEMM up to ~2 passes
+            # — every pass writes its rows of ONE [n, m] output per layer (no concatenation kernels)
+            if any(_codec_key(l)[0] == "single" for l in layers):
+                return [l(x2) for l in layers]
+            full = [torch.empty((n, l.out_features), dtype=torch.float32, device=x2.device) for l in layers]
+            for i in range(0, n, fused):
+                multi_gemv(layers, x2[i:i + fused], outs=[f[i:i + fused] for f in full])
+            return full
+        return [l(x2) for l in layers]  # decode-to-fp16 + GEMM path of the modules
     results = [None] * len(layers)
     mixed_kv = x_rot is None and n <= 8 and not accumulate  # the any-KV / mixed-family kernels: no rotation, batch <= 8
     for idxs in launch_groups(layers, mixed_kv):

@@ -12,6 +12,9 @@ class PackedLinearBase(nn.Module):
     in_features: int
     out_features: int
     max_fused_batch = GEMV_MAX_BATCH  # tensor-core-order families raise this to 64 (8 MFMA column groups; 32 under a 128 KiB image)
+    # up to this batch the forward runs ceil(bs / max_fused_batch) passes of the fused kernel instead of decode-to-HBM + GEMM:
+    # measured on Llama-8B shapes the passes win up to ~2 x 64 rows; 0: no chunked passes (SIMT packings)
+    max_chunked_batch = 0
 
     def _gemv(self, x, bs):  # -> [bs, m] (fp32 or fp16)
         raise NotImplementedError
@@ -33,6 +36,9 @@ class PackedLinearBase(nn.Module):
         bs = x.shape[0]
         if bs <= self.max_fused_batch:
             y = self._gemv(x, bs)
+        elif bs <= self.max_chunked_batch:
+            from . import multi_gemv  # passes of the fused launch, each writing its rows of one [bs, m] output
+            y = multi_gemv([self], x)[0]
         else:
             with torch.no_grad():
                 dq = self.get_weight()

@@ -51,6 +51,7 @@ class VQLinearPackTensorCore(_VQBase):
         idx = lut_bits if vec_sz == 2 else (2 * lut_bits if lut_bits <= 6 else lut_bits)
         if (4 << (idx + min(15 - idx, 5))) > 64 * 1024:
             self.max_fused_batch = 32
+        self.max_chunked_batch = 2 * self.max_fused_batch
         self.register_ops()
 
     def op_names(self):

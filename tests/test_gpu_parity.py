@@ -302,7 +302,10 @@ def test_early_and_late_staging_agree(qp):
             if len(layers) > 1:
                 assert len({getattr(l, "tlut" if hasattr(l, "tlut") else "lut").data_ptr() for l in layers}) == len(layers)
             for a, b in zip(shared, qp.multi_gemv(layers, x)):
-                assert torch.equal(a, b), (qstr, n)
+                if n <= 8:
+                    assert torch.equal(a, b), (qstr, n)
+                else:  # batched kernel (csrc/tc_gemm.h): K split over up to 16 workgroups, fp32 atomics -> summation order varies
+                    assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * float(a.abs().max())), (qstr, n)
 
 
 def test_prezero_and_out_zeroed(qp, oracle):
@@ -610,17 +613,20 @@ def test_comb_layer_row_shards(qp, oracle):
         assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max())), world
 
 
-@pytest.mark.parametrize("qstr,k,m,n", [("tcomb_6_7_0.5_none_0.9", 4096, 4096, 128), ("tcq_6_none_0.9", 14336, 4096, 128),
-                                        ("ldlq_2_12_none_1.0", 4096, 1024, 48), ("ldlq_1_4_none_1.0", 4096, 2048, 128),
+@pytest.mark.parametrize("qstr,k,m,n", [("tcomb_6_7_0.5_none_0.9", 4096, 4096, 128), ("tcq_6_none_0.9", 14336, 4096, 100),
+                                        ("ldlq_2_12_none_1.0", 4096, 1024, 48), ("ldlq_1_4_none_1.0", 4096, 2048, 65),
+                                        ("tcomb_6_7_0.5_none_0.9", 4096, 4096, 129), ("tcq_6_none_0.9", 14336, 4096, 200),
+                                        ("ldlq_2_12_none_1.0", 4096, 1024, 80), ("ldlq_1_4_none_1.0", 4096, 2048, 256),
                                         ("tcomb_6_7_0.5_none_0.9", 4096, 14336, 1024)])
 def test_module_path_above_the_fused_batch(qp, oracle, qstr, k, m, n):
-    """The path the perplexity eval takes (bs = 8192 there: eval_qdict.py:17-38): above max_fused_batch the module decodes W to
-    fp16 (bit-exact, checked elsewhere) and multiplies with the fp16 GEMM, as the reference does for bs > 8
-    (lib/linear/tcq_linear.py:75-84).  Against the oracle's fp64 GEMM on the oracle's W: fp32 accumulation + ONE fp16 rounding
-    of the output."""
+    """Above max_fused_batch the module runs passes of the fused kernel up to max_chunked_batch (2 x 64 rows) and beyond that the
+    path the perplexity eval takes (bs = 8192 there: eval_qdict.py:17-38): W decoded to fp16 (bit-exact, checked elsewhere)
+    times the fp16 GEMM, as the reference does for bs > 8 (lib/linear/tcq_linear.py:75-84).  Both against the oracle's fp64 GEMM
+    on the oracle's W: fp32 accumulation + ONE fp16 rounding of the output."""
     info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=11)
     layer = qp.make_linear_from_info(qstr, info).cuda()
     assert n > layer.max_fused_batch
+    assert layer.max_chunked_batch == 2 * layer.max_fused_batch
     W = _oracle_weight(oracle, qstr, info, m, k)
     x = torch.randn(n, k, generator=torch.Generator().manual_seed(n)).half()
     y = layer(x.cuda())
