@@ -6,6 +6,10 @@
 #include "tc_chain.h"
 using namespace qpal;
 
+// (MAC = 0: every decoded pair must reach the result, or the compiler drops its gather — the round-2 version folded only .x
+// of each fragment, i.e. one pair in four, and its "56 wave-steps/us" was not a decode rate)
+__device__ __forceinline__ uint32_t xor4(u32x4 v) { return v.x ^ v.y ^ v.z ^ v.w; }
+
 template <class Codec, int W, int MAC, int PIPE>
 __global__ __launch_bounds__(64 * W) void k(const uint32_t *tab, uint32_t *out, int iters) {
     __shared__ __attribute__((aligned(16))) uint32_t lut[Codec::LDS_DWORDS];
@@ -33,14 +37,14 @@ __global__ __launch_bounds__(64 * W) void k(const uint32_t *tab, uint32_t *out, 
             xb[0][1] = u32x4{*(const uint32_t *)(row + 16), *(const uint32_t *)(row + 18), *(const uint32_t *)(row + 24), *(const uint32_t *)(row + 26)};
             if (PIPE) {
                 if (MAC) mfma_step(af[d], xb, acc);
-                else static_for<0, 8>([&](auto ic) { fold ^= __builtin_bit_cast(u32x4, af[d][decltype(ic)::value]).x; });
+                else static_for<0, 8>([&](auto ic) { fold ^= xor4(__builtin_bit_cast(u32x4, af[d][decltype(ic)::value])); });
                 __builtin_amdgcn_sched_barrier(0);
                 decode_step<Codec>(lut, laneoff, w, af[d]);
             } else {
                 half8_t a[8];
                 decode_step<Codec>(lut, laneoff, w, a);
                 if (MAC) mfma_step(a, xb, acc);
-                else static_for<0, 8>([&](auto ic) { fold ^= __builtin_bit_cast(u32x4, a[decltype(ic)::value]).x; });
+                else static_for<0, 8>([&](auto ic) { fold ^= xor4(__builtin_bit_cast(u32x4, a[decltype(ic)::value])); });
             }
 #pragma unroll
             for (int i = 0; i < Codec::NW; i++) w[i] = w[i] * 1664525u + 1013904223u;  // 2 VALU per packed word: new bits every step

@@ -710,6 +710,9 @@ __global__ __launch_bounds__(1024) void lm_head_argmax_kernel(const LmHeadParams
             const int vi = __builtin_bit_cast(int, red[16 + w]);
             if (v > b || (v == b && vi < bi)) b = v, bi = vi;
         }
+        // NaN or all -inf logits (a diverged step) leave no row selected: the token must still be a VALID row — the harness
+        // feeds it to the next step's embedding lookup on the device (torch.argmax returns an in-range index there too)
+        if ((unsigned)bi >= (unsigned)p.vocab) bi = 0;
         *p.token = bi;
         __hip_atomic_store(as_global(reinterpret_cast<unsigned *>(p.ws + 2 * gridDim.x)), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

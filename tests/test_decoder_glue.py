@@ -310,6 +310,36 @@ def test_lm_head_argmax_one_launch(qp, vocab, k, eps):
         assert int(tok[0]) == min(7, t)
 
 
+@pytest.mark.parametrize("case", ["nan", "neg_inf"])
+def test_lm_head_argmax_degenerate_logits_give_a_valid_token(qp, case):
+    """A diverged step (NaN in the residual stream, or every logit -inf) selects no row by comparison; the token written must
+    still be a valid row index — the harness uses it as an embedding index on the device in the next graph replay
+    (ADVICE r2).  torch.argmax returns an in-range index in both cases as well (0 for all -inf)."""
+    dev = torch.device("cuda", 0)
+    nat = qp._native
+    vocab, k = 5000, 4096
+    gen = torch.Generator(device=dev).manual_seed(1)
+    W = (torch.randn(vocab, k, device=dev, generator=gen) * 0.05).half()
+    h = torch.zeros(k, device=dev)
+    if case == "nan":
+        h[:] = torch.randn(k, device=dev, generator=gen)
+        h[17] = float("nan")
+    else:  # x = e_0: every logit is W[r][0] = -inf
+        h[0] = 1.0
+        W[:, 0] = float("-inf")
+        W[:, 1:] = 0
+    wsb = nat.lib().qpal_lm_head_ws_bytes(vocab)
+    ws = torch.zeros(wsb // 4, device=dev)
+    tok = torch.full((1,), -1, dtype=torch.long, device=dev)
+    for rep in range(2):
+        nat.check(nat.lib().qpal_lm_head_argmax(h.data_ptr(), None, 0.0, W.data_ptr(), None, tok.data_ptr(), ws.data_ptr(), wsb, vocab, k,
+                                                torch.cuda.current_stream(dev).cuda_stream), "qpal_lm_head_argmax")
+        torch.cuda.synchronize()
+        assert 0 <= int(tok[0]) < vocab
+    if case == "neg_inf":
+        assert int(tok[0]) == int((W.float() @ h.half().float()).argmax()) == 0
+
+
 @pytest.mark.parametrize("model", ["3_8b", "3_70b"])
 def test_fused_decode_step_matches_modular_step(qp, model):
     """perf/decode_llama.py: the fused-glue step (6 launches per layer; 9 where the hidden width's rotation cannot run inside the
