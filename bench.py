@@ -238,9 +238,52 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
                 outs += qp.multi_gemv(part.layers, part.x, outs=part.outs, outs_zeroed=part.outs_zeroed, prezero=part.prezero)
         return outs
 
+    # Batched token (8 < n <= fused batch, multi-job launches): the lockstep GEMM kernel splits K of every launch kind, so every
+    # output must start at zero.  The harness owns the buffers, as a decode loop would: the outputs of a launch are consecutive
+    # blocks of one allocation, zeroed by the launch BEFORE it (prezero) — one memset node per token instead of five per layer.
+    # Up to max_chunked_batch the batch goes through each launch kind in passes of <= 64 rows (the second pass re-reads weights the
+    # first has just pulled through L2 / the Infinity Cache).
+    batched = (gather is None and launch in ("multi", "chain") and parts is None and only_kind is None and 8 < n
+               and all(n <= max(m.max_fused_batch, m.max_chunked_batch) and type(m) in qp.linear._PACKED_KEYS
+                       for groups in layers for grp in groups for m, _, _ in grp))
+    blocks = None
+    if batched:
+        blocks = []
+        for groups in layers:
+            per = []
+            for grp in groups:
+                ms = [m.out_features for m, _, _ in grp]
+                flat = torch.empty(n * sum(ms), dtype=torch.float32, device=device)
+                views, off = [], 0
+                for m_ in ms:
+                    views.append(flat[off: off + n * m_].view(n, m_))
+                    off += n * m_
+                per.append((flat, views))
+            blocks.append(per)
+
+    def token_batched():
+        outs = []
+        seq = [(li, gi) for li in range(len(layers)) for gi in range(4)]
+        for idx, (li, gi) in enumerate(seq):
+            grp = layers[li][gi]
+            flat, views = blocks[li][gi]
+            nxt = blocks[seq[idx + 1][0]][seq[idx + 1][1]][0] if idx + 1 < len(seq) else None
+            mods = [m for m, _, _ in grp]
+            step = min(m.max_fused_batch for m in mods)
+            for i in range(0, n, step):
+                rows = [v[i:i + step] for v in views]
+                if no_prezero:
+                    qp.multi_gemv(mods, xs[grp[0][1]][i:i + step], outs=rows)
+                else:
+                    qp.multi_gemv(mods, xs[grp[0][1]][i:i + step], outs=rows, outs_zeroed=idx > 0, prezero=nxt if i == 0 else None)
+            outs += views
+        return outs
+
     def token():
         if parts is not None:
             return token_chain()
+        if batched:
+            return token_batched()
         outs = []
         if hasattr(gather, "new_token"):
             gather.new_token()  # the same call sites take the same peer-gather slots in every (captured) token

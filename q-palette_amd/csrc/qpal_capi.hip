@@ -22,7 +22,7 @@ int waves_of(int nbg) { return gemv_waves<1>() == 8 ? 8 : (nbg >= 4 ? 8 : 16); }
 // workgroups one launch round can hold: one per CU; two with the 8-wave experiment build (tc_kernels.h QPAL_W8), whose
 // batch <= 16 kernels leave room for a second workgroup's LDS and registers
 int round_capacity(int waves) {
-#ifdef QPAL_W8
+#if defined(QPAL_W8) && !defined(QPAL_W8_ONE)
     return waves == 8 ? 2 * kNumCU : kNumCU;   // (the wide-batch kernels use 256 VGPRs: they would also fit twice, LDS allowing)
 #else
     (void)waves;
@@ -323,6 +323,37 @@ int launch_tcq_gemm(const TcMultiParams &mp, int S, int KV1, int KV2, int nbg, i
                     : launch_tcq_gemm_nbg8(mp, S, KV1, KV2, grid, stream);
 }
 
+// Zeroing of the split-K outputs of a multi-job launch: contiguous [n][m] outputs that follow each other in memory (how
+// qpalette_amd.ops allocates the outputs of one launch) are zeroed by ONE memset node — a node costs ~5 us inside a graph, more
+// than filling a megabyte.
+int zero_split_jobs(const TcMultiParams &mp, const int *ms, const int *zeroed, hipStream_t stream) {
+    struct Span { char *p; size_t bytes; };
+    Span spans[kMaxJobs];
+    int ns = 0;
+    for (int j = 0; j < mp.njobs; j++) {
+        const TcParams &p = mp.job[j];
+        if (p.act_out || p.sk <= 1 || zeroed[j] || p.accumulate) continue;
+        if (p.ldo != ms[j]) {  // a column block of a wider buffer: its own 2-D fill
+            int rc = zero_if_split(p, ms[j], stream, 0);
+            if (rc) return rc;
+            continue;
+        }
+        spans[ns++] = Span{reinterpret_cast<char *>(p.out), sizeof(float) * (size_t)ms[j] * p.n};
+    }
+    for (int i = 1; i < ns; i++)  // insertion sort by address
+        for (int k = i; k > 0 && spans[k].p < spans[k - 1].p; k--) { Span t = spans[k]; spans[k] = spans[k - 1]; spans[k - 1] = t; }
+    for (int i = 0; i < ns;) {
+        char *p0 = spans[i].p;
+        size_t bytes = spans[i].bytes;
+        int k = i + 1;
+        while (k < ns && spans[k].p == p0 + bytes) bytes += spans[k++].bytes;
+        hipError_t e = hipMemsetAsync(p0, 0, bytes, stream);
+        if (e != hipSuccess) return (int)e;
+        i = k;
+    }
+    return 0;
+}
+
 int tcq_gemv_one(float *out, long ldo, const void *c1, const void *c2, const void *x, const void *tlut, int m, int n,
                  int k, int k1, int k2, int S, int KV1, int KV2, hipStream_t stream) {
     TcMultiParams mp{};
@@ -442,12 +473,15 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
     const bool gemm = !mixed && use_gemm(nbg, mp);
     if (gemm) plan_gemm(mp, grid);
     else plan_launch(mp, zeroed, grid, waves_of(nbg));
+    int ms[kMaxJobs] = {0};
     for (int j = 0; j < njobs; j++) {
-        if (mp.job[j].act_out) {  // the SwiGLU epilogue pairs two supertile rows of one workgroup and has no split-K form
-            if (mp.job[j].sk != 1 || (waves_of(nbg) >> mp.job[j].log2_wpr) < 2) return QPAL_E_SHAPE;
-            continue;
-        }
-        int rc = zero_if_split(mp.job[j], jobs[j].m, s, jobs[j].out_zeroed);
+        ms[j] = jobs[j].m;
+        zeroed[j] = jobs[j].out_zeroed;
+        // the SwiGLU epilogue pairs two supertile rows of one workgroup and has no split-K form
+        if (mp.job[j].act_out && (mp.job[j].sk != 1 || (waves_of(nbg) >> mp.job[j].log2_wpr) < 2)) return QPAL_E_SHAPE;
+    }
+    {
+        int rc = zero_split_jobs(mp, ms, zeroed, s);
         if (rc) return rc;
     }
     if (gemm) return launch_tcq_gemm(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, nbg, grid, s);
@@ -561,12 +595,14 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
     const bool gemm = use_gemm(nbg, mp);
     if (gemm) plan_gemm(mp, grid);
     else plan_launch(mp, zeroed, grid, waves_of(nbg));
+    int ms[kMaxJobs] = {0};
     for (int j = 0; j < njobs; j++) {
-        if (mp.job[j].act_out) {
-            if (mp.job[j].sk != 1 || (waves_of(nbg) >> mp.job[j].log2_wpr) < 2) return QPAL_E_SHAPE;
-            continue;
-        }
-        int rc = zero_if_split(mp.job[j], jobs[j].m, s, jobs[j].out_zeroed);
+        ms[j] = jobs[j].m;
+        zeroed[j] = jobs[j].out_zeroed;
+        if (mp.job[j].act_out && (mp.job[j].sk != 1 || (waves_of(nbg) >> mp.job[j].log2_wpr) < 2)) return QPAL_E_SHAPE;
+    }
+    {
+        int rc = zero_split_jobs(mp, ms, zeroed, s);
         if (rc) return rc;
     }
     if (gemm) return launch_lut_tc_gemm(mp, bits, vec, nbg, grid, s);

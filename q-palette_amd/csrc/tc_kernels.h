@@ -92,6 +92,34 @@ struct TcMultiParams {
     TcParams job[kMaxJobs];
 };
 
+// Codebook image build shared by the codecs: chunk c (16 bytes = 4 copies of one entry) of the image comes from table entry
+// (4 c) >> LOG2C.  U table reads of a thread are issued together, then written.  Round 3 measured U on one box (perf/ab_wrap.sh,
+// profiles/r03_ab_buildU.txt): the plain read-then-write loop (U = 1: one L2 round trip per chunk, 5-8 per launch that builds
+// its image after the argument fetch) looked like 2 us of exposed latency in the rotating kernels' prologue — but with U = 3 / 8
+// the token behind the incoherence wrapper got SLOWER (604 -> 597 / 573 tok/s; whole-model step 477 -> 474 / 459) and the
+// batched kernel did not move (17 050 -> 17 120): the image build is not on the critical path (the x -> stage 1 -> barrier ->
+// stage 2 chain of the rotation is), and a burst of table reads from every CU at once delays exactly those x loads.  U = 1.
+#ifndef QPAL_BUILD_U
+#define QPAL_BUILD_U 1
+#endif
+constexpr int kBuildInFlight = QPAL_BUILD_U;
+template <int CHUNKS, int LOG2C, int U, class Entry>
+__device__ __forceinline__ void build_image(uint32_t *lds, int tid, int nthreads, Entry &&entry) {
+    for (int c0 = tid; c0 < CHUNKS; c0 += U * nthreads) {
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int c = c0 + u * nthreads;
+            v[u] = entry(((c < CHUNKS ? c : 0) * 4) >> LOG2C);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int c = c0 + u * nthreads;
+            if (c < CHUNKS) reinterpret_cast<u32x4 *>(lds)[c] = u32x4{v[u], v[u], v[u], v[u]};
+        }
+    }
+}
+
 // ================================================================================================
 // TCQ codec.  Bit surgery on one lane's KV dwords (reference lanes A = bits [0,16KV), B = [16KV,32KV))
 // for tile group G = ksub*2 + msub; state I in 0..7 (0..3 = lane A's j, 4..7 = lane B's j).
@@ -130,11 +158,9 @@ struct TcqCodec {
     static __device__ __forceinline__ uint32_t entry(const void *tab, int e) {
         return as_global(static_cast<const uint32_t *>(tab))[e & ((1 << S) - 1)] ^ (((uint32_t)e >> S) << 15);
     }
+    template <int U = kBuildInFlight>  // table reads in flight per thread
     static __device__ __forceinline__ void build(uint32_t *lds, const void *tab, int tid, int nthreads) {
-        for (int c = tid; c < CHUNKS; c += nthreads) {
-            const uint32_t v = entry(tab, (c * 4) >> LOG2C);
-            reinterpret_cast<u32x4 *>(lds)[c] = u32x4{v, v, v, v};
-        }
+        build_image<CHUNKS, LOG2C, U>(lds, tid, nthreads, [&](int e) { return entry(tab, e); });
     }
 
     // (A << L4) | B in the low 2*L4 bits (KV <= 4 only: 2*L4 <= 32)
@@ -236,11 +262,9 @@ struct LutCodec {
         else if constexpr (PAIR) return (uint32_t)l16[e & ((1 << BITS) - 1)] | ((uint32_t)l16[e >> BITS] << 16);
         else return l16[e];
     }
+    template <int U = kBuildInFlight>  // table reads in flight per thread
     static __device__ __forceinline__ void build(uint32_t *lds, const void *tab, int tid, int nthreads) {
-        for (int c = tid; c < CHUNKS; c += nthreads) {
-            const uint32_t v = entry(tab, (c * 4) >> LOG2C);
-            reinterpret_cast<u32x4 *>(lds)[c] = u32x4{v, v, v, v};
-        }
+        build_image<CHUNKS, LOG2C, U>(lds, tid, nthreads, [&](int e) { return entry(tab, e); });
     }
 
     template <int G>
@@ -290,7 +314,7 @@ struct StreamView {
 // Experiment (make VARIANT=w8 EXTRA=-DQPAL_W8): TWO 8-wave workgroups per CU instead of one 16-wave one for the
 // batch <= 16 kernels — 64 KiB image + 15 KiB scratch each (x fits only for n * k <= ~7000: the k = 4096 launches at batch 1),
 // 128 VGPRs as before (4 waves per SIMD).  No fused rotation in this build.
-#ifdef QPAL_W8
+#if defined(QPAL_W8) && !defined(QPAL_W8_ONE)  // (QPAL_W8_ONE: ONE 8-wave workgroup per CU — half the waves to dispatch — keeps the full scratch)
 constexpr int kScratchBytes = 15 * 1024;
 #else
 constexpr int kScratchBytes = 31 * 1024;  // LDS left beside the 128 KiB codebook image: reduction buffer + x

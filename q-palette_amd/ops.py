@@ -235,6 +235,17 @@ def _prezero_args(prezero):
     return prezero.data_ptr(), prezero.numel() * prezero.element_size()
 
 
+def _fresh_outs(ms, n, device):
+    """Fresh fp32 [n, m_j] outputs of one launch as consecutive blocks of ONE allocation: where the launch splits K (float
+    atomics into a zeroed output) the library then zeroes all of them with one memset node instead of one per output."""
+    flat = torch.empty(n * sum(ms), dtype=torch.float32, device=device)
+    outs, off = [], 0
+    for m in ms:
+        outs.append(flat[off: off + n * m].view(n, m))
+        off += n * m
+    return outs
+
+
 def _out_arg(outs, j, n, m, device):
     """fp32 [n, m] destination: a fresh tensor, or the caller's (row stride >= m allowed: a column block of a
     wider [n, sum m] buffer)."""
@@ -322,6 +333,9 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
     _chk(x_rms is None or x_rot is not None, "x_rms needs x_rot (the RMSNorm is fused into the rotation's input)")
     jobs = (nat.TcqJob * len(streams))()
     results, keep = [], [xh, x32]
+    if outs is None and act_outs is None and len(streams) > 1:
+        outs = _fresh_outs([st[3] for st in streams], n, x.device)
+        outs_zeroed = False
     for j, stream in enumerate(streams):
         c1, c2, tlut, m = stream[:4]
         kv = stream[4] if len(stream) > 4 else 0
@@ -369,6 +383,9 @@ def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezer
     _chk(x_rms is None or x_rot is not None, "x_rms needs x_rot (the RMSNorm is fused into the rotation's input)")
     jobs = (nat.LutJob * len(layers))()
     results, keep = [], [xh, x32]
+    if outs is None and act_outs is None and len(layers) > 1:
+        outs = _fresh_outs([l[2] for l in layers], n, x.device)
+        outs_zeroed = False
     for j, (q, lut, m) in enumerate(layers):
         q, cb = _lut_args(q, lut, m, k, bits, vec)
         act = _act_arg(act_outs, j, n, m, x.device)
