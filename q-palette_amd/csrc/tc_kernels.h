@@ -93,12 +93,14 @@ struct TcMultiParams {
 };
 
 // Codebook image build shared by the codecs: chunk c (16 bytes = 4 copies of one entry) of the image comes from table entry
-// (4 c) >> LOG2C.  U table reads of a thread are issued together, then written.  Round 3 measured U on one box (perf/ab_wrap.sh,
-// profiles/r03_ab_buildU.txt): the plain read-then-write loop (U = 1: one L2 round trip per chunk, 5-8 per launch that builds
-// its image after the argument fetch) looked like 2 us of exposed latency in the rotating kernels' prologue — but with U = 3 / 8
-// the token behind the incoherence wrapper got SLOWER (604 -> 597 / 573 tok/s; whole-model step 477 -> 474 / 459) and the
-// batched kernel did not move (17 050 -> 17 120): the image build is not on the critical path (the x -> stage 1 -> barrier ->
-// stage 2 chain of the rotation is), and a burst of table reads from every CU at once delays exactly those x loads.  U = 1.
+// (4 c) >> LOG2C.  U table reads of a thread are issued together, then written.  Round 3 measured the alternatives on one box
+// each (perf/ab_wrap.sh; profiles/r03_ab_buildU.txt, r03_ab_image_build_forms.txt): the plain read-then-write loop (U = 1: one L2
+// round trip per chunk, 5-8 per launch that builds its image after the argument fetch) looked like 2 us of exposed latency in
+// the rotating kernels' prologue — but U = 3 / 8 made the token behind the incoherence wrapper SLOWER (604 -> 597 / 573 tok/s;
+// whole-model step 477 -> 474 / 459), delaying the batch by s_sleep made it slower by the delay, and one read per SOURCE entry
+// (512 instead of 4 096 reads of the 2 KiB table, its 8 chunk writes in a burst, early staging for every image size) cost the
+// wrapper 3.4 % and the plain token 0.6 % (and moved the k / v latency-table entries of the 128 KiB images by -0.9 ... +1.1 us).
+// The slow trickle of this loop stays out of the way of the loads and LDS traffic that ARE on the critical path.  U = 1.
 #ifndef QPAL_BUILD_U
 #define QPAL_BUILD_U 1
 #endif
