@@ -511,7 +511,15 @@ def main():
     if args.incoherent:
         build_incoherent_state()
 
-    nrot = [0]  # rotation launches of one token (beyond the SwiGLU one of every layer)
+    nrot = [0]  # rotation launches of one token (launches of their own: qpal_hadamard)
+
+    def k28_ok(mod, k, K):
+        if n != 1 or not qp.ops.can_fuse_rotation(1, k, K) or type(mod) not in qp.linear._PACKED_KEYS:
+            return False
+        if isinstance(mod, qp.VQLinearPackTensorCore):
+            idx = mod.lut_bits if mod.vec_sz == 2 else (2 * mod.lut_bits if mod.lut_bits <= 6 else mod.lut_bits)
+            return (4 << (idx + min(15 - idx, 5))) >= 40 * 1024
+        return qp.linear._codec_key(mod)[0] != "single"
 
     def token_incoherent():
         """[rotate -> one multi-job GEMV with fused Wscale*scale] x 4 per layer; down_proj's rotation also applies
@@ -520,7 +528,7 @@ def main():
         scale = 64.0
         nrot[0] = 0
         for groups, per in zip(layers, inc):
-            pre, ug = {}, None
+            pre, ug, act_signed = {}, None, False
             for gi, (grp, pi) in enumerate(zip(groups, per)):
                 mods = [m for m, _, _ in grp]
                 wsc = pi["wscale"]
@@ -533,14 +541,25 @@ def main():
                     nxt = groups[3][0][0].out_features
                     if not args.no_prezero:
                         pre[3] = torch.empty((n, nxt), dtype=torch.float32, device=device)
+                    dmod, dpi = groups[3][0][0], per[3]
+                    fuse28 = (dpi["K"] > 1 and not args.no_fuse_rotation and len(groups[3]) == 1 and k28_ok(dmod, groups[3][0][1], dpi["K"]))
+                    # (with the fused 14336-wide rotation the epilogue also applies down_proj's sign vector: exact, and the rotation
+                    # inside every down_proj workgroup then reads one vector instead of two)
                     qp.multi_gemv([pi["il"]], xs[grp[0][1]], wscales=[pi["il_w"]], oscale=scale, x_rot=(pi["su"], 1 / scale),
-                                  prezero=pre.get(3), act_out=act)
+                                  prezero=pre.get(3), act_out=act, act_su=dpi["su"] if fuse28 else None)
+                    act_signed = fuse28
                     ug = act
                     outs.append(act)
                     continue
-                if gi == 3:
+                if (gi == 3 and ug.dtype == torch.float16 and pi["K"] > 1 and not args.no_fuse_rotation and len(mods) == 1
+                        and k28_ok(mods[0], grp[0][1], pi["K"])):
+                    # the 28 x 512 rotation of the activation inside down_proj's own x staging (csrc/rot_k28.h)
+                    xr = ug
+                    kw["x_rot"] = (None if act_signed else pi["su"], 1 / scale, pi["hadK"], pi["K"])
+                elif gi == 3:
                     xr = had.rotate(ug, hadK=pi["hadK"], K=pi["K"], su=pi["su"], post_scale=1 / scale,
                                     in_mode=had.IN_F16 if ug.dtype == torch.float16 else had.IN_SWIGLU_F32)
+                    nrot[0] += 1
                 elif pi["K"] == 1 and not args.no_fuse_rotation and qp.linear.rotation_fusable(mods, n):
                     xr = xs[grp[0][1]]
                     kw["x_rot"] = (pi["su"], 1 / scale)
@@ -654,9 +673,10 @@ def main():
                 torch.cuda.synchronize()
                 w2 = time.perf_counter() - t1
             extra = {"value": args.steps * n / w2, "unit": "tokens/s", "ms_per_step": w2 / args.steps * 1e3,
-                     "rotation_launches_per_token": nlayers + nrot[0],
-                     "what": "same token, every projection group behind sign flip + Hadamard + scales (rotation fused into "
-                             "the GEMV x staging for k = 4096, one SwiGLU+rotation launch per layer for down_proj)"}
+                     "rotation_launches_per_token": nrot[0],
+                     "what": "same token, every projection group behind sign flip + Hadamard + scales (rotation fused into the GEMV x "
+                             "staging: k = 4096 on the matrix pipe, the 28 x 512 transform of down_proj's 14336-wide input likewise; SwiGLU "
+                             "in the gate|up epilogue)"}
         except Exception as exc:  # the headline line must not depend on this leg
             extra = {"error": repr(exc)}
 
@@ -695,7 +715,7 @@ def main():
                    "linears_per_token": nlinear, "launches_per_token": nlaunch, "phases_per_token": nphase,
                    "launch_mode": args.launch,
                    "incoherent": bool(args.incoherent),
-                   "rotation_launches_per_token": (nlayers + nrot[0]) if args.incoherent else 0},
+                   "rotation_launches_per_token": nrot[0] if args.incoherent else 0},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
                      "traffic_source": traffic_source(),

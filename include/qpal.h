@@ -98,6 +98,14 @@ typedef struct qpal_tcq_job {
                           it from the two layers); the epilogue then writes fp16(silu(fp16 gate)) * fp16 up — the
                           `act_fn(gate) * up` of lib/linear/incoherent_linear.py:333 — here and `out` is not written
                           (may be NULL).  The following rotation reads 2 bytes per element instead of 8 and evaluates no SwiGLU */
+    /* x_had with a NON-power-of-two width (round 3): x_K = 28 and k = 14336 = 28 * 512 (the down_proj input of Llama-3.1-8B):
+     * the staging applies (hadK (x) H_512) / sqrt(k) with the reference's fp16 rounding between the two factors
+     * (lib/utils/matmul_had.py:137-148); x_hadk: fp16 [28][28], y[j] = sum_i x_hadk[j][i] t[i] (what qpal_hadamard takes).
+     * Batch 1, fp16 x, no RMSNorm; qpal_can_fuse_rotation_k(n, k, K) says where.  x_K = 0 / 1: power-of-two widths as before. */
+    const void *x_hadk;
+    int x_K;
+    const void *act_su; /* with act_out: fp16 [m / 2] of +-1, multiplied into the activation written — the `* SU` in front of the NEXT
+                           projection's rotation (exact: a sign flip), so that rotation reads one vector instead of two; or NULL */
 } qpal_tcq_job;
 /* prezero/prezero_bytes (may be NULL/0): a buffer this launch also fills with zeros, for a LATER launch on the
  * same stream that accumulates into it with atomics (split-K of a few-rows x long-K layer such as down_proj).
@@ -137,6 +145,9 @@ typedef struct qpal_lut_job {
     const void *x_rms_w;
     int accumulate;
     void *act_out;     /* as in qpal_tcq_job */
+    const void *x_hadk; /* as in qpal_tcq_job */
+    int x_K;
+    const void *act_su;
 } qpal_lut_job;
 int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits, int vec, void *prezero,
                            long prezero_bytes, void *stream);
@@ -306,6 +317,8 @@ int qpal_attn_rope_decode(const float *q, const float *k, const float *v, void *
 /* 1 if the GEMV entry points can apply the rotation themselves (x_had): k in {2048, 4096} at batch 1 (the
  * decode case); 0 otherwise (then call qpal_hadamard first). */
 int qpal_can_fuse_rotation(int n, int k);
+/* the same for x_K > 1 (K = 28, k = 14336, batch 1; codecs whose codebook image is >= 40 KiB: every TCQ codec) */
+int qpal_can_fuse_rotation_k(int n, int k, int K);
 
 const char *qpal_error_string(int code);
 int qpal_version(void);

@@ -110,6 +110,7 @@ def main(argv=None, quiet=False):
     ap.add_argument("--torch-lm-head", action="store_true", help="fused step: final norm, lm_head and argmax as torch ops (hipBLASLt GEMV)")
     ap.add_argument("--no-split-attention", action="store_true", help="one workgroup per query head at every context length")
     ap.add_argument("--no-modular", action="store_true", help="time the fused-glue step only (profiling)")
+    ap.add_argument("--no-k28-fusion", action="store_true", help="fused step: down_proj's 28 x 512 rotation as a launch of its own (round 2)")
     args = ap.parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("needs a GPU")
@@ -211,6 +212,17 @@ def main(argv=None, quiet=False):
             setattr(mod, name, (None if hk is None else hk.T.contiguous().half().to(dev), K))
         return getattr(mod, name)
 
+    def k28_in_gemv(mlp):
+        """down_proj's rotation inside its own launch: k = 14336 = 28 x 512, a tensor-core-order layer whose codebook image can lend
+        the rotation its scratch (every TCQ codec; --no-k28-fusion: the qpal_hadamard launch of round 2)."""
+        if args.no_k28_fusion or mlp.inter_K <= 1 or not qp.ops.can_fuse_rotation(1, mlp.intermediate_size, mlp.inter_K):
+            return False
+        d = mlp.down_proj
+        if isinstance(d, qp.VQLinearPackTensorCore):
+            idx = d.lut_bits if d.vec_sz == 2 else (2 * d.lut_bits if d.lut_bits <= 6 else d.lut_bits)
+            return (4 << (idx + min(15 - idx, 5))) >= 40 * 1024
+        return isinstance(d, (qp.QTIPLinearTCQ, qp.CombtLinearTCQ)) and qp.linear._codec_key(d)[0] != "single"
+
     def fused_layer(idx, layer, mask):
         att, mlp = layer.self_attn, layer.mlp
         proj, wsc, blocks = att._qkv_layout()
@@ -251,8 +263,15 @@ def main(argv=None, quiet=False):
                 qp.share_codebooks([il, mlp.down_proj] + ugl)
                 mlp._ug_il = il
                 mlp._ug_il_w = qp.linear.interleave_rows(mlp.Wscale_ug[:inter], mlp.Wscale_ug[inter:])
+            fuse28 = k28_in_gemv(mlp)
+            # with the fused rotation the gate|up epilogue also applies down_proj's sign vector (a sign flip: exact), so the rotation
+            # inside every down_proj workgroup reads one 28 KiB vector instead of two
             qp.multi_gemv([mlp._ug_il], h32, wscales=[mlp._ug_il_w], oscale=mlp.scale, x_rot=(mlp.SU_ug, 1.0 / mlp.scale),
-                          x_rms=(eps, layer.post_attention_layernorm.weight), act_out=act16)
+                          x_rms=(eps, layer.post_attention_layernorm.weight), act_out=act16, act_su=mlp.SU_dp if fuse28 else None)
+            if fuse28:  # the 28 x 512 rotation inside down_proj's x staging (csrc/rot_k28.h): no launch of its own
+                qp.multi_gemv([mlp.down_proj], act16, outs=[h32], wscales=[mlp.Wscale_dp], oscale=mlp.scale,
+                              x_rot=(None, 1.0 / mlp.scale, mlp.had_left_dp_T, mlp.inter_K), accumulate=True)
+                return
             xr = qp.hadamard.rotate(act16, hadK=mlp.had_left_dp_T, K=mlp.inter_K, su=mlp.SU_dp, post_scale=1.0 / mlp.scale)
             qp.multi_gemv([mlp.down_proj], xr, outs=[h32], wscales=[mlp.Wscale_dp], oscale=mlp.scale,
                           accumulate=True)
@@ -334,7 +353,7 @@ def main(argv=None, quiet=False):
         t_fused = timed_fused()
         # kernel launches of one fused step: per layer q|k|v (+ its rotation where the GEMV cannot rotate), attention, o (+ rotation),
         # up|gate (+ rotation), SwiGLU rotation, down; + the norm / lm_head / argmax launch (the embedding row copy is a memcpy node)
-        per_layer = 6 if rot_in_gemv else 9
+        per_layer = (5 if k28_in_gemv(layers[0].mlp) else 6) if rot_in_gemv else 9
         if not quiet:
             print(json.dumps({"model": args.model, "layers": nlayers, "quantizer": args.qdict or args.quantizer, "context": args.context,
                               "tokens_per_s_fused_glue": 1.0 / t_fused, "ms_fused_glue": t_fused * 1e3}))

@@ -21,7 +21,7 @@ class TcqJob(ctypes.Structure):
                 ("out_zeroed", _I), ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long),
                 ("x_had", _I), ("x_post", _F), ("x_su", _P), ("kv", _I),
                 ("x_f32", _P), ("x_f32_scale", _F), ("x_fresh", _I), ("publish", _I),
-                ("x_rms_eps", _F), ("x_rms_w", _P), ("accumulate", _I), ("kv2", _I), ("act_out", _P)]
+                ("x_rms_eps", _F), ("x_rms_w", _P), ("accumulate", _I), ("kv2", _I), ("act_out", _P), ("x_hadk", _P), ("x_K", _I), ("act_su", _P)]
 
 
 class LutJob(ctypes.Structure):
@@ -29,7 +29,7 @@ class LutJob(ctypes.Structure):
     _fields_ = [("out", _P), ("qweight", _P), ("x", _P), ("lut", _P), ("m", _I), ("k", _I), ("out_zeroed", _I),
                 ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long), ("x_had", _I), ("x_post", _F), ("x_su", _P),
                 ("x_f32", _P), ("x_f32_scale", _F), ("x_fresh", _I), ("publish", _I),
-                ("x_rms_eps", _F), ("x_rms_w", _P), ("accumulate", _I), ("act_out", _P)]
+                ("x_rms_eps", _F), ("x_rms_w", _P), ("accumulate", _I), ("act_out", _P), ("x_hadk", _P), ("x_K", _I), ("act_su", _P)]
 
 
 class ChainPhase(ctypes.Structure):
@@ -56,6 +56,7 @@ _SIGNATURES = {
     "qpal_lut_simt_dequant": [_P, _P, _P, _I, _I, _I, _I, _P],
     "qpal_tc_to_simt": [_P, _P, _I, _I, _I, _I, _P],
     "qpal_can_fuse_rotation": [_I, _I],
+    "qpal_can_fuse_rotation_k": [_I, _I, _I],
     "qpal_pack_tcq": [_P, _P, _I, _I, _I],
     "qpal_pack_tcq_states": [_P, _P, _I, _I, _I],
     "qpal_pack_lut_tc": [_P, _P, _I, _I, _I, _I],

@@ -68,10 +68,31 @@ bool rot_ok(int n, int k) {
     return n == 1 && (k == 2048 || k == 4096) && x_fits_lds(n, k);
 }
 
+// the 14336-wide rotation inside the staging (rot_k28.h): batch 1, x in LDS, a codebook image that can lend 40 KiB
+bool rot_k28_ok(int n, int k, int K, int image_bytes) {
+#ifdef QPAL_W8
+    return false;
+#endif
+    return n == 1 && K == kK28 && k == kN28 && x_fits_lds(n, k) && image_bytes >= kP28 * kTbRow;
+}
+
 // x_had of a job -> kernel parameters; QPAL_E_SHAPE where the fused rotation is not available
 int set_rotation(TcParams &p, int x_had, const void *x_su, float x_post, int n, int k, const void *x_f32 = nullptr,
-                 float x_rms_eps = 0.f, const void *x_rms_w = nullptr) {
+                 float x_rms_eps = 0.f, const void *x_rms_w = nullptr, const void *x_hadk = nullptr, int x_K = 0,
+                 int image_bytes = 64 * 1024) {
     if (!x_had) return (x_f32 || x_rms_eps > 0.f) ? QPAL_E_PARAM : QPAL_OK;  // fp32 / normalised input: rotation staging only
+    if (x_K > 1) {
+        if (!rot_k28_ok(n, k, x_K, image_bytes)) return QPAL_E_SHAPE;
+        if (!x_hadk || !p.x) return QPAL_E_NULL;
+        if (x_f32 || x_rms_eps > 0.f) return QPAL_E_PARAM;
+        if (!aligned(p.x, 16) || (x_su && !aligned(x_su, 16)) || !aligned(x_hadk, 2)) return QPAL_E_ALIGN;
+        p.x_rot = kK28;
+        p.x_hadk = static_cast<const uint16_t *>(x_hadk);
+        p.x_su = static_cast<const uint16_t *>(x_su);
+        p.x_pre = (float)(1.0 / sqrt((double)k));
+        p.x_post = x_post;
+        return QPAL_OK;
+    }
     if (!rot_ok(n, k)) return QPAL_E_SHAPE;
     if (x_su && !aligned(x_su, 16)) return QPAL_E_ALIGN;
     if (x_f32) {
@@ -443,10 +464,11 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
                      jb.oscale);
         mp.job[j].kv = kv;
         mp.job[j].kv2 = job_two ? jb.kv2 : 0;
-        rc = set_rotation(mp.job[j], jb.x_had, jb.x_su, jb.x_post, n, jb.k, jb.x_f32, jb.x_rms_eps, jb.x_rms_w);
+        rc = set_rotation(mp.job[j], jb.x_had, jb.x_su, jb.x_post, n, jb.k, jb.x_f32, jb.x_rms_eps, jb.x_rms_w, jb.x_hadk, jb.x_K);
         if (rc) return rc;
         mp.job[j].accumulate = jb.accumulate ? 1 : 0;
         mp.job[j].act_out = static_cast<uint16_t *>(jb.act_out);
+        mp.job[j].act_su = jb.act_out ? static_cast<const uint16_t *>(jb.act_su) : nullptr;
         zeroed[j] = jb.act_out ? 1 : jb.out_zeroed;  // (nothing to zero: `out` is not written; split-K is refused below)
     }
     // the kernel stages (or rotates) x once per distinct x pointer: jobs that share x must agree on how
@@ -454,8 +476,11 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         for (int i = 0; i < j; i++)
             if (mp.job[i].x == mp.job[j].x &&
                 (jobs[i].x_had != jobs[j].x_had || jobs[i].x_su != jobs[j].x_su || jobs[i].x_post != jobs[j].x_post ||
-                 jobs[i].k != jobs[j].k || jobs[i].x_rms_eps != jobs[j].x_rms_eps || jobs[i].x_rms_w != jobs[j].x_rms_w))
+                 jobs[i].k != jobs[j].k || jobs[i].x_rms_eps != jobs[j].x_rms_eps || jobs[i].x_rms_w != jobs[j].x_rms_w ||
+                 jobs[i].x_K != jobs[j].x_K || jobs[i].x_hadk != jobs[j].x_hadk))
                 return QPAL_E_PARAM;
+    for (int j = 1; j < njobs; j++)  // one kernel per launch: the 14336-wide rotation has its own instantiation
+        if ((mp.job[j].x_rot == kK28) != (mp.job[0].x_rot == kK28)) return QPAL_E_PARAM;
     if (mixed) {
         if (n > 8) return QPAL_E_SHAPE;
         for (int j = 0; j < njobs; j++) {
@@ -574,18 +599,23 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
         if (jb.wscale && !aligned(jb.wscale, 2)) return QPAL_E_ALIGN;
         if (jb.ldo != 0 && jb.ldo < jb.m) return QPAL_E_SHAPE;
         lut_fill(mp.job[j], jb.out, jb.ldo ? jb.ldo : jb.m, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k, jb.wscale, jb.oscale);
-        rc = set_rotation(mp.job[j], jb.x_had, jb.x_su, jb.x_post, n, jb.k, jb.x_f32, jb.x_rms_eps, jb.x_rms_w);
+        rc = set_rotation(mp.job[j], jb.x_had, jb.x_su, jb.x_post, n, jb.k, jb.x_f32, jb.x_rms_eps, jb.x_rms_w, jb.x_hadk, jb.x_K,
+                          lut_image_bytes(bits, vec));
         if (rc) return rc;
         mp.job[j].accumulate = jb.accumulate ? 1 : 0;
         mp.job[j].act_out = static_cast<uint16_t *>(jb.act_out);
+        mp.job[j].act_su = jb.act_out ? static_cast<const uint16_t *>(jb.act_su) : nullptr;
         zeroed[j] = jb.act_out ? 1 : jb.out_zeroed;
     }
     for (int j = 1; j < njobs; j++)
         for (int i = 0; i < j; i++)
             if (mp.job[i].x == mp.job[j].x &&
                 (jobs[i].x_had != jobs[j].x_had || jobs[i].x_su != jobs[j].x_su || jobs[i].x_post != jobs[j].x_post ||
-                 jobs[i].k != jobs[j].k || jobs[i].x_rms_eps != jobs[j].x_rms_eps || jobs[i].x_rms_w != jobs[j].x_rms_w))
+                 jobs[i].k != jobs[j].k || jobs[i].x_rms_eps != jobs[j].x_rms_eps || jobs[i].x_rms_w != jobs[j].x_rms_w ||
+                 jobs[i].x_K != jobs[j].x_K || jobs[i].x_hadk != jobs[j].x_hadk))
                 return QPAL_E_PARAM;
+    for (int j = 1; j < njobs; j++)
+        if ((mp.job[j].x_rot == kK28) != (mp.job[0].x_rot == kK28)) return QPAL_E_PARAM;
     mp.zero = static_cast<u32x4 *>(prezero);
     mp.zero_chunks = (int)(prezero_bytes / 16);
     int grid;
@@ -846,6 +876,10 @@ int qpal_chain_launch(const void *dev_blob, const void *host_blob, void *dev_ws,
 }
 
 int qpal_can_fuse_rotation(int n, int k) { return n >= 1 && k > 0 && rot_ok(n, k) ? 1 : 0; }
+int qpal_can_fuse_rotation_k(int n, int k, int K) {
+    if (K <= 1) return qpal_can_fuse_rotation(n, k);
+    return rot_k28_ok(n, k, K, 64 * 1024) ? 1 : 0;
+}
 
 const char *qpal_error_string(int code) {
     switch (code) {

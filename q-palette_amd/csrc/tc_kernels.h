@@ -26,6 +26,7 @@
 #pragma once
 #include "qpal_common.h"
 #include "wht64.h"
+#include "rot_k28.h"
 
 namespace qpal {
 
@@ -58,7 +59,8 @@ struct TcParams {
     int lut_bits, lut_vec;   // TcqMix kernels only: != 0: this job is a VQ/SQ (LutCodec<lut_bits, lut_vec>) layer; kv = its dwords per lane
     const uint16_t *x_su;    // gemv prologue rotation (x_rot != 0): fp16 [k] sign vector or null
     float x_pre, x_post;     //   staged x = fp16( fp16( H_k (x * su) * x_pre ) * x_post ), x_pre = k^-1/2
-    int x_rot;               //   0: x is used as given; else k / 1024 (k in {2048, 4096}), needs x_lds
+    int x_rot;               //   0: x is used as given; else k / 1024 (k in {2048, 4096}), or 28: the 14336-wide rotation of rot_k28.h; needs x_lds
+    const uint16_t *x_hadk;  //   x_rot == 28: fp16 [28][28]
     const uint16_t *wscale;  // gemv epilogue: fp16 [m] per-output-row scale or null
     float oscale;            // gemv epilogue: out = acc * wscale[row] * oscale
     unsigned long long *dbg;  // QPAL_STAMPS diagnostic builds only: per-wave s_memtime stamps
@@ -73,6 +75,8 @@ struct TcParams {
     float x_rms_eps;         // > 0: x <- x * rsqrt(mean(x^2) + eps) (* x_rms_w) before the sign flip (fp32, then ONE fp16 rounding)
     const uint16_t *x_rms_w; // fp16 [k] RMSNorm weight or null
     int accumulate;          // out += result instead of out = result
+    const uint16_t *act_su;  // with act_out: fp16 [m / 2] signs (+-1) multiplied into the activation written (the `x * SU_dp` of the NEXT projection's
+                             // wrapper, lib/linear/incoherent_linear.py:336: exact, so the consumer's rotation need not read SU)
     uint16_t *act_out;       // ROT kernels, batch 1: the layer's supertile rows alternate up / gate (u0 g0 u1 g1 ...): the epilogue
                              // writes fp16 silu(gate) * up [m / 2] here instead of `out` (rows per workgroup >= 2, no split-K)
 };
@@ -571,7 +575,9 @@ inline TcEarly early_args(const TcMultiParams &mp) {
     return e;
 }
 
-template <class C1, class C2, int NBG, bool ROT = false>
+// ROT: 0 plain; 1: can rotate x while staging it (k = 2048 / 4096, wht64.h); 2: the 14336-wide rotation of rot_k28.h (its own
+// instantiation: its registers would make the other rotating launches spill)
+template <class C1, class C2, int NBG, int ROT = 0>
 __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const void *etab, int en, int ek, int eon,
                                                        const TcMultiParams mp) {
     constexpr bool TWO = !std::is_void_v<C2>;
@@ -745,8 +751,24 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         if (p.tab != cur_tab || (x_lds && p.x != cur_x)) {  // workgroup-uniform
             if (x_lds && p.x != cur_x) {
                 const int total = p.n * p.k;  // multiple of 8 halves
-                if (ROT && p.x_rot) {
-                  if constexpr (ROT) {
+                if (ROT == 2 && p.x_rot == 28) {
+                  if constexpr (ROT == 2 && C1::LDS_DWORDS * 4 >= kP28 * kTbRow) {
+                    // down_proj of Llama-3.1-8B: (hadK(28) (x) H_512) of the 14336-vector on all 16 waves (rot_k28.h); its 40 KiB of
+                    // scratch alias the codebook image, whose table entries are requested first and written afterwards
+                    constexpr int NVR = C1::CHUNKS / 1024;
+                    uint32_t ev[NVR];
+                    rot_k28(p.x, p.x_su, p.x_hadk, p.x_pre, p.x_post, xs, reinterpret_cast<unsigned char *>(lut), wave, lane,
+                            [](int i) { return xs_index(i); }, [&] {
+#pragma unroll
+                                for (int r = 0; r < NVR; r++) ev[r] = C1::entry(p.tab, ((tid + r * 1024) * 4) >> C1::LOG2C);
+                            });
+#pragma unroll
+                    for (int r = 0; r < NVR; r++) reinterpret_cast<u32x4 *>(lut)[tid + r * 1024] = u32x4{ev[r], ev[r], ev[r], ev[r]};
+                    if (tid < 32) xs[total + tid] = 0;
+                    cur_tab = p.tab;
+                  }
+                } else if (ROT == 1 && p.x_rot) {
+                  if constexpr (ROT == 1) {
                     // Incoherence rotation fused into the staging (wht64.h: Walsh-Hadamard transform on the matrix pipe).
                     wht_float4 *d1buf = reinterpret_cast<wht_float4 *>(xs + ((total + 32 + 7) & ~7));  // <= 16 KiB
                     // RMSNorm fused into the rotation (decoder-block fusion).  The transform is linear, so the norm's scalar
@@ -916,7 +938,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
             if (srow < p.nrows) {
                 // the incoherent wrappers' `* Wscale * scale`, fused
                 const float osc = p.wscale ? p.oscale * (float)__builtin_bit_cast(_Float16, (uint16_t)wraw) : p.oscale;
-                if constexpr (ROT) {
+                if constexpr (ROT == 1) {
                     if (p.act_out) {  // SwiGLU of an interleaved up | gate layer: threads (rl, r) and (rl + 1, r) are lanes r, r + 32
                         float v = 0.f;
                         for (int qq = 0; qq < wpr; qq++) v += red[((rl << p.log2_wpr) + qq) * 32 + r];
@@ -924,7 +946,9 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                         const float gate = __shfl_down(mine, 32, 64);
                         if ((rl & 1) == 0) {
                             const float sg = (float)(_Float16)(gate * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gate * -1.44269504f)));
-                            p.act_out[(long)(srow >> 1) * 32 + r] = __builtin_bit_cast(uint16_t, (_Float16)(sg * mine));
+                            uint16_t av = __builtin_bit_cast(uint16_t, (_Float16)(sg * mine));
+                            if (p.act_su) av ^= p.act_su[(long)(srow >> 1) * 32 + r] & 0x8000u;  // * (+-1): flip the sign bit
+                            p.act_out[(long)(srow >> 1) * 32 + r] = av;
                         }
                         continue_item = true;
                     }

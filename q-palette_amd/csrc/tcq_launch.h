@@ -7,7 +7,7 @@
 
 namespace qpal {
 
-template <int S, int KV1, int KV2, int NBG, bool ROT = false>
+template <int S, int KV1, int KV2, int NBG, int ROT = 0>
 static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
     [[maybe_unused]] const TcParams &p = mp.job[0];
     const TcEarly e = early_args(mp);

@@ -167,7 +167,7 @@ def rotation_fusable(layers, n):
 
 
 def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=None, oscale=1.0, x_rot=None, x_rms=None,
-               accumulate=False, act_out=None):
+               accumulate=False, act_out=None, act_su=None):
     """y_i = layers[i](x) for several quantized linears that share the input, batch <= 8.  Layers of one
     kind and codec (e.g. q|k|v or gate|up of one block) go out as ONE kernel launch per codec
     (C-ABI qpal_*_gemv_multi); anything else is one launch per layer.  Returns fp32/fp16 [n, m_i] tensors in
@@ -183,7 +183,10 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
     None) applies the RMSNorm in front of the rotation (decoder-block fusion).  accumulate: outs[i] += y_i (the residual add:
     outs[i] holds the residual stream; the launch may split K on its own: the atomics add onto the live output, outs_zeroed is ignored).
     act_out (fp16 [1, m / 2]; one layer built by interleave_up_gate, batch 1, x_rot): the launch's epilogue writes
-    silu(gate) * up there and no fp32 output (returns [None])."""
+    silu(gate) * up there and no fp32 output (returns [None]); act_su (fp16 [m / 2] of +-1): multiplied into it — the sign flip in
+    front of the NEXT projection's rotation, which then reads one vector instead of two.
+    x_rot = (su, post, hadK, K) with K = 28 on a k = 14336 layer: the (hadK (x) H_512) rotation of a down_proj input inside the
+    launch's x staging (ops.can_fuse_rotation(n, k, K))."""
     from .. import ops
 
     x2 = x.reshape(-1, layers[0].in_features)
@@ -192,7 +195,7 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
         if len(layers) != 1 or n != 1 or x_rot is None or accumulate or outs is not None:
             raise RuntimeError("multi_gemv: act_out needs ONE interleaved up|gate layer, batch 1 and x_rot")
         layer = layers[0]
-        common = dict(prezero=prezero, wscales=wscales, oscale=oscale, x_rot=x_rot, x_rms=x_rms, act_outs=[act_out])
+        common = dict(prezero=prezero, wscales=wscales, oscale=oscale, x_rot=x_rot, x_rms=x_rms, act_outs=[act_out], act_su=act_su)
         if isinstance(layer, QTIPLinearTCQ):
             ops.tcq_gemv_multi([(layer.trellis, None, layer.tlut, layer.out_features)], x2, layer.tlut_bits, layer.KV, **common)
         elif isinstance(layer, CombtLinearTCQ) and layer.use_comb_kernel:

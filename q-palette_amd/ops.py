@@ -246,6 +246,14 @@ def _fresh_outs(ms, n, device):
     return outs
 
 
+def _act_su_arg(act_su, act, m):
+    if act_su is None or act is None:
+        return None
+    _chk(act_su.is_cuda and act_su.is_contiguous() and act_su.dtype == torch.float16 and act_su.numel() == m // 2,
+         f"act_su must be a contiguous fp16 CUDA vector of {m // 2} signs")
+    return act_su.data_ptr()
+
+
 def _out_arg(outs, j, n, m, device):
     """fp32 [n, m] destination: a fresh tensor, or the caller's (row stride >= m allowed: a column block of a
     wider [n, sum m] buffer)."""
@@ -272,19 +280,29 @@ def _wscale_arg(wscales, j, m):
 
 
 def _rot_args(x_rot, xh, k):
-    """x_rot = (su or None, post_scale): the kernel rotates x itself (C-ABI x_had).  -> (x_had, x_post, x_su ptr)"""
+    """x_rot = (su or None, post_scale[, hadK, K]): the kernel rotates x itself (C-ABI x_had; with hadK fp16 [K, K] and K = 28 the
+    14336-wide (hadK (x) H_512) rotation of a down_proj input).  -> (x_had, x_post, x_su ptr, x_hadk ptr, x_K)"""
     if x_rot is None:
-        return 0, 1.0, None
-    su, post = x_rot
-    _chk(bool(nat.lib().qpal_can_fuse_rotation(xh.shape[0], k)),
-         f"the rotation cannot be fused for batch {xh.shape[0]}, k = {k} (use hadamard.rotate first)")
+        return 0, 1.0, None, None, 0
+    su, post = x_rot[:2]
+    hadk, K = (x_rot[2], int(x_rot[3])) if len(x_rot) > 2 and x_rot[2] is not None else (None, 0)
+    if K > 1:
+        _chk(bool(nat.lib().qpal_can_fuse_rotation_k(xh.shape[0], k, K)),
+             f"the rotation cannot be fused for batch {xh.shape[0]}, k = {k}, K = {K} (use hadamard.rotate first)")
+        _chk(hadk.is_cuda and hadk.is_contiguous() and hadk.dtype == torch.float16 and tuple(hadk.shape) == (K, K),
+             f"x_rot hadK must be a contiguous fp16 CUDA matrix [{K}, {K}]")
+    else:
+        _chk(bool(nat.lib().qpal_can_fuse_rotation(xh.shape[0], k)),
+             f"the rotation cannot be fused for batch {xh.shape[0]}, k = {k} (use hadamard.rotate first)")
     if su is not None:
         _chk(su.is_cuda and su.is_contiguous() and su.dtype == torch.float16 and su.numel() == k,
              f"x_rot sign vector must be a contiguous fp16 CUDA vector of {k} elements")
-    return 1, float(post), (su.data_ptr() if su is not None else None)
+    return 1, float(post), (su.data_ptr() if su is not None else None), (hadk.data_ptr() if K > 1 else None), (K if K > 1 else 0)
 
 
-def can_fuse_rotation(n, k):
+def can_fuse_rotation(n, k, K=1):
+    if K > 1:
+        return bool(nat.lib().qpal_can_fuse_rotation_k(int(n), int(k), int(K)))
     return bool(nat.lib().qpal_can_fuse_rotation(int(n), int(k)))
 
 
@@ -317,7 +335,7 @@ def _rms_args(x_rms, k):
 
 
 def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=False, prezero=None, wscales=None,
-                   oscale=1.0, x_rot=None, x_rms=None, accumulate=False, act_outs=None):
+                   oscale=1.0, x_rot=None, x_rms=None, accumulate=False, act_outs=None, act_su=None):
     """Several TCQ GEMVs of one codec and one input in ONE launch (C-ABI qpal_tcq_gemv_multi).
     streams: list of (c1, c2_or_None, tlut, m), (c1, None, tlut, m, KV) or (c1, c2, tlut, m, KV, KV2): with per-stream KV, layers of
     one codebook size but different bit widths — single-stream and column-split (combt) ones — share the launch.  x: [n, k].  Returns the list of fp32 [n, m] outputs.
@@ -328,7 +346,7 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
     n, k = x.shape
     _chk(1 <= n <= MAX_FUSED_BATCH, "batch size must be in 1..64")
     xh, x32 = _x_arg(x, x_rot)
-    had, xpost, xsu = _rot_args(x_rot, x, k)
+    had, xpost, xsu, xhadk, xK = _rot_args(x_rot, x, k)
     rms_eps, rms_w = _rms_args(x_rms, k)
     _chk(x_rms is None or x_rot is not None, "x_rms needs x_rot (the RMSNorm is fused into the rotation's input)")
     jobs = (nat.TcqJob * len(streams))()
@@ -361,7 +379,7 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
                              1 if (outs is not None and outs_zeroed) else 0,
                              _wscale_arg(wscales, j, m), float(oscale), _ldo(out, n, m) if out is not None else 0, had, xpost, xsu, kv,
                              x32.data_ptr() if x32 is not None else None, 1.0, 0, 0, rms_eps, rms_w, 1 if accumulate else 0, kv2,
-                             act.data_ptr() if act is not None else None)
+                             act.data_ptr() if act is not None else None, xhadk, xK, _act_su_arg(act_su, act, m))
         results.append(out)
         keep += [c1, c2, tl]
     zp, zb = _prezero_args(prezero)
@@ -372,13 +390,13 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
 
 
 def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezero=None, wscales=None, oscale=1.0,
-                      x_rot=None, x_rms=None, accumulate=False, act_outs=None):
+                      x_rot=None, x_rms=None, accumulate=False, act_outs=None, act_su=None):
     """Several VQ/SQ (tensor-core packing) GEMVs of one codec and one input in ONE launch.
     layers: list of (qweight, lut, m); x: [n, k].  outs / outs_zeroed / prezero as in tcq_gemv_multi."""
     n, k = x.shape
     _chk(1 <= n <= MAX_FUSED_BATCH, "batch size must be in 1..64")
     xh, x32 = _x_arg(x, x_rot)
-    had, xpost, xsu = _rot_args(x_rot, x, k)
+    had, xpost, xsu, xhadk, xK = _rot_args(x_rot, x, k)
     rms_eps, rms_w = _rms_args(x_rms, k)
     _chk(x_rms is None or x_rot is not None, "x_rms needs x_rot (the RMSNorm is fused into the rotation's input)")
     jobs = (nat.LutJob * len(layers))()
@@ -394,7 +412,7 @@ def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezer
                              cb.data_ptr(), m, k, 1 if (outs is not None and outs_zeroed) else 0, _wscale_arg(wscales, j, m),
                              float(oscale), _ldo(out, n, m) if out is not None else 0, had, xpost, xsu,
                              x32.data_ptr() if x32 is not None else None, 1.0, 0, 0, rms_eps, rms_w, 1 if accumulate else 0,
-                             act.data_ptr() if act is not None else None)
+                             act.data_ptr() if act is not None else None, xhadk, xK, _act_su_arg(act_su, act, m))
         results.append(out)
         keep += [q, cb]
     zp, zb = _prezero_args(prezero)

@@ -250,6 +250,12 @@ def test_swiglu_in_the_gemv_epilogue(qp, qstr, inter):
     ref = (torch.nn.functional.silu(g.half().float()).half().float() * u.half().float()).half()
     act = torch.full((1, inter), float("nan"), dtype=torch.float16, device=dev)
     (none,) = qp.multi_gemv([il], x, wscales=[qp.linear.interleave_rows(wu, wg)], oscale=scale, x_rot=(su, 1.0 / scale), act_out=act)
+    # act_su: the NEXT projection's sign vector applied by this epilogue (exact: a sign flip)
+    sdn = (torch.randint(0, 2, (inter,), device=dev, generator=gen) * 2 - 1).half()
+    act_s = torch.empty_like(act)
+    qp.multi_gemv([il], x, wscales=[qp.linear.interleave_rows(wu, wg)], oscale=scale, x_rot=(su, 1.0 / scale), act_out=act_s, act_su=sdn)
+    torch.cuda.synchronize()
+    assert torch.equal(act_s, act * sdn)
     torch.cuda.synchronize()
     assert none is None and bool(torch.isfinite(act).all())
     # same fp32 sums (the interleaved layer is planned like the pair), silu through the hardware reciprocal: <= 1-2 fp16 ulps

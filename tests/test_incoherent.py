@@ -449,6 +449,71 @@ def test_fused_rotation_equals_separate_launch(qp, oracle, k, n=1):
 
 
 @gpu
+def test_fused_14336_rotation_in_the_down_proj_staging(qp, oracle):
+    """x_rot = (su, post, hadK, 28) on a k = 14336 layer: the GEMV's x staging applies (hadK(28) (x) H_512) / sqrt(k) with the
+    reference's fp16 rounding between the factors (csrc/rot_k28.h; lib/utils/matmul_had.py:137-148) instead of a qpal_hadamard
+    launch in front of every down_proj.
+    (1) The staged vector itself, read back through a SELECTION layer (5-bit scalar codes, lut = {0, 1, ...}: row r of W is the
+        unit vector e_sel[r], so y[r] = x'[sel[r]] exactly): within 1 fp16 ulp of the oracle's restatement of the reference
+        pipeline, almost everywhere identical.
+    (2) Real layers: equal to the plain GEMV on the oracle-rotated input (the same decode and summation order) up to those rare
+        ulps, and within the module bound of the oracle's float64 result."""
+    k, K = 14336, 28
+    rng = np.random.default_rng(28)
+    act = (rng.standard_normal((1, k)) * 0.7).astype(np.float16)
+    su = _signs(rng, k)
+    hk, KK = qp.hadamard.get_hadK(k)
+    assert KK == K
+    hadk_T = hk.T.contiguous().half()          # what IncoherentMLP passes (had_left_dp_T)
+    scale = 48.0
+    want = oi.left_input(act, su, hadk_T.numpy().astype(np.float64), scale)   # y[j] = sum_i M[j][i] t[i], M as passed
+    actd, sud, hkd = torch.from_numpy(act).cuda(), torch.from_numpy(su).cuda(), hadk_T.cuda()
+    assert qp.ops.can_fuse_rotation(1, k, K) and not qp.ops.can_fuse_rotation(2, k, K) and not qp.ops.can_fuse_rotation(1, 4096, K)
+    # (1) selection layer: blocks j = 0, 13, 27 whole + 512 random positions
+    sel = np.concatenate([np.arange(0, 512), np.arange(13 * 512, 14 * 512), np.arange(27 * 512, 28 * 512),
+                          rng.choice(k, 512, replace=False)]).astype(np.int64)
+    m = sel.size
+    idx = torch.zeros((m, k), dtype=torch.int32)
+    idx[torch.arange(m), torch.from_numpy(sel)] = 1
+    lut = torch.zeros(32, dtype=torch.float16)
+    lut[1] = 1.0
+    lut[2:] = torch.linspace(-3, 3, 30).half()
+    info = {"in_features": k, "out_features": m, "lut_bits": 5, "vec_sz": 1, "bias": None, "dtype": torch.float16,
+            "qweight": qp.packers.pack_qweight(idx, 1, 5), "lut": lut.view(32, 1)}
+    layer = qp.VQLinearPackTensorCore.gen_layer_from_info(info).cuda()
+    (y,) = qp.multi_gemv([layer], actd, x_rot=(sud, 1 / scale, hkd, K))
+    got = y.cpu().numpy()[0]
+    _assert_ulp(got, want[0, sel])
+    assert np.mean(got == want[0, sel]) > 0.999   # measured: every element identical (fp32 vs float64 sums differ at exact ties only)
+    # the sign vector may also have been applied by the producer (act_su of the gate|up epilogue): same staged vector
+    (y2,) = qp.multi_gemv([layer], (actd * sud), x_rot=(None, 1 / scale, hkd, K))
+    assert torch.equal(y, y2)
+    # (the separate launch, qpal_hadamard, keeps fp32 between the two factors: it differs from the reference pipeline's rounding
+    # of the intermediate in ~40 % of the elements, by design — test_rotate_vs_oracle holds it to its own bound)
+    # (2) real down_proj layers
+    x_or = torch.from_numpy(want.astype(np.float16)).cuda()
+    for qstr in ("tcomb_6_7_0.5_0_1", "tcq_6_0_1", "ldlq_2_12_0_1"):
+        linfo = _info(qp, k, 1024, qstr, 90)
+        lay = qp.make_linear(linfo).cuda()
+        ws = linfo["Wscale"].cuda()
+        (fused,) = qp.multi_gemv([lay], actd, wscales=[ws], oscale=scale, x_rot=(sud, 1 / scale, hkd, K))
+        (plain,) = qp.multi_gemv([lay], x_or, wscales=[ws], oscale=scale)
+        acc, mag = _lin(oracle, linfo, want)
+        wsn = linfo["Wscale"].numpy().astype(np.float64) * scale
+        _close(fused.cpu().numpy(), acc * wsn, mag * wsn, qstr)
+        assert torch.equal(fused, plain), qstr   # the same staged vector, the same decode and summation order
+        # accumulate (the residual add of the decoder block) through the same launch
+        h = torch.randn(1, 1024, device="cuda")
+        acc_buf = h.clone()
+        qp.multi_gemv([lay], actd, outs=[acc_buf], wscales=[ws], oscale=scale, x_rot=(sud, 1 / scale, hkd, K), accumulate=True)
+        assert torch.allclose(acc_buf, h + fused, atol=1e-4 * float(fused.abs().max()) + 1e-6)
+    # codecs whose image is smaller than the rotation's 40 KiB of scratch are refused (callers rotate with qpal_hadamard)
+    small = qp.make_linear(_info(qp, k, 256, "ldlq_2_8_0_1", 91)).cuda()
+    with pytest.raises(RuntimeError):
+        qp.multi_gemv([small], actd, x_rot=(sud, 1 / scale, hkd, K))
+
+
+@gpu
 @pytest.mark.parametrize("n", [1, 20])
 def test_incoherent_mlp_70b_shapes_and_large_batch(qp, oracle, n):
     """Llama-70B sizes (hidden 8192: rotation in a launch of its own; intermediate 28672 = 28 * 1024: two-launch K > 1 path)
