@@ -238,12 +238,13 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
                 outs += qp.multi_gemv(part.layers, part.x, outs=part.outs, outs_zeroed=part.outs_zeroed, prezero=part.prezero)
         return outs
 
-    # Batched token (8 < n <= fused batch, multi-job launches): the lockstep GEMM kernel splits K of every launch kind, so every
+    # Batched token (4 <= n <= fused batch, multi-job launches): the lockstep GEMM kernel splits K of every launch kind, so every
     # output must start at zero.  The harness owns the buffers, as a decode loop would: the outputs of a launch are consecutive
     # blocks of one allocation, zeroed by the launch BEFORE it (prezero) — one memset node per token instead of five per layer.
     # Up to max_chunked_batch the batch goes through each launch kind in passes of <= 64 rows (the second pass re-reads weights the
     # first has just pulled through L2 / the Infinity Cache).
-    batched = (gather is None and launch in ("multi", "chain") and parts is None and only_kind is None and 8 < n
+    batched = (gather is None and launch in ("multi", "chain") and parts is None and only_kind is None
+               and n >= int(os.environ.get("QPAL_GEMM_MIN_BATCH", "4"))
                and all(n <= max(m.max_fused_batch, m.max_chunked_batch) and type(m) in qp.linear._PACKED_KEYS
                        for groups in layers for grp in groups for m, _, _ in grp))
     blocks = None

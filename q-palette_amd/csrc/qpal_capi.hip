@@ -233,7 +233,11 @@ void plan_gemm(TcMultiParams &mp, int &grid) {
 // 1 (default): the lockstep kernel with the step's activations shared through LDS (tc_gemm.h)
 bool use_gemm(int nbg, const TcMultiParams &mp) {
     static const int on = env_int("QPAL_GEMM", 1);
-    if (!on || nbg < 2) return false;
+    // the lockstep kernel from this batch on (measured, Llama-8B tcomb_6_7, ms per step old / new: batch 2 1.38 / 1.50, 3 1.48 / 1.51,
+    // 4 1.68 / 1.51, 6 1.89 / 1.53, 8 2.09 / 1.55: profiles/r03_sweep_minbatch.txt)
+    static const int min_n = env_int("QPAL_GEMM_MIN_BATCH", 4);
+    if (!on || mp.job[0].n < min_n) return false;
+    (void)nbg;
     for (int j = 0; j < mp.njobs; j++) {
         const TcParams &p = mp.job[j];
         if (!aligned(p.x, 16) || (p.k % 8) || p.x_rot || p.act_out) return false;
@@ -339,7 +343,8 @@ int zero_if_split(const TcParams &p, int m, hipStream_t stream, int out_zeroed =
 }
 
 int launch_tcq_gemm(const TcMultiParams &mp, int S, int KV1, int KV2, int nbg, int grid, hipStream_t stream) {
-    return nbg == 2 ? launch_tcq_gemm_nbg2(mp, S, KV1, KV2, grid, stream)
+    return nbg == 1 ? launch_tcq_gemm_nbg1(mp, S, KV1, KV2, grid, stream)
+         : nbg == 2 ? launch_tcq_gemm_nbg2(mp, S, KV1, KV2, grid, stream)
          : nbg == 4 ? launch_tcq_gemm_nbg4(mp, S, KV1, KV2, grid, stream)
                     : launch_tcq_gemm_nbg8(mp, S, KV1, KV2, grid, stream);
 }

@@ -81,9 +81,9 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
     constexpr int NCH = NBG * 8 * 16;                   // 16-byte chunks of one step's x tile
     constexpr int CPT = (NCH + NT - 1) / NT;            // chunks per thread
     constexpr int NWMAX = C1::NW > CB::NW ? C1::NW : CB::NW;
-    static_assert(2 * XBUF >= W * 1024, "the x buffers double as the epilogue's per-wave transposition scratch");
+    constexpr int XT = 2 * XBUF >= W * 1024 ? 2 * XBUF : W * 1024;  // the x buffers double as the epilogue's per-wave transposition scratch
     __shared__ __attribute__((aligned(16))) uint32_t lut[C1::LDS_DWORDS];
-    __shared__ __attribute__((aligned(16))) unsigned char xt[2 * XBUF];
+    __shared__ __attribute__((aligned(16))) unsigned char xt[XT];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -5,6 +5,7 @@
 namespace qpal {
 int launch_tcq_gemv(const TcMultiParams &p, int S, int KV1, int KV2, int nbg, int grid, hipStream_t stream);
 int launch_tcq_gemv_wide(const TcMultiParams &p, int S, int KV1, int KV2, int nbg, int grid, hipStream_t stream);
+int launch_tcq_gemm_nbg1(const TcMultiParams &p, int S, int KV1, int KV2, int grid, hipStream_t stream);
 int launch_tcq_gemm_nbg2(const TcMultiParams &p, int S, int KV1, int KV2, int grid, hipStream_t stream);
 int launch_tcq_gemm_nbg4(const TcMultiParams &p, int S, int KV1, int KV2, int grid, hipStream_t stream);
 int launch_tcq_gemm_nbg8(const TcMultiParams &p, int S, int KV1, int KV2, int grid, hipStream_t stream);

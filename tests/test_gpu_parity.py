@@ -302,9 +302,9 @@ def test_early_and_late_staging_agree(qp):
             if len(layers) > 1:
                 assert len({getattr(l, "tlut" if hasattr(l, "tlut") else "lut").data_ptr() for l in layers}) == len(layers)
             for a, b in zip(shared, qp.multi_gemv(layers, x)):
-                if n <= 8:
+                if n < 4:
                     assert torch.equal(a, b), (qstr, n)
-                else:  # batched kernel (csrc/tc_gemm.h): K split over up to 16 workgroups, fp32 atomics -> summation order varies
+                else:  # batched kernel (csrc/tc_gemm.h, batch >= 4): K split over up to 32 workgroups, fp32 atomics -> summation order varies
                     assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * float(a.abs().max())), (qstr, n)
 
 
