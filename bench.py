@@ -785,8 +785,8 @@ def whole_model_leg(args):
     return {"value": 1e3 / r["ms_fused_glue"], "unit": "tokens/s", "ms_per_step": r["ms_fused_glue"],
             "launches_per_token": r["launches_per_token"], "context": 1024,
             "what": "whole-model greedy decode step, batch 1: embedding + every decoder block on the fused glue (RMSNorm + rotation "
-                    "inside the q|k|v and up|gate launches, rope + cache append + attention as one launch, residual adds inside "
-                    "o / down) + final norm, fp16 lm_head and argmax as one launch; HIP-graph replay; "
+                    "inside the q|k|v and up|gate launches, rope + cache append + attention as one launch, the 28 x 512 rotation and "
+                    "the residual adds inside o / down) + final norm, fp16 lm_head and argmax as one launch; HIP-graph replay; "
                     "the reference times the same thing as generate() (eval/measure_latency.py:236-272)"}
 
 
