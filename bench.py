@@ -117,9 +117,21 @@ def spawn_ranks(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p_ in procs:
-        rc = max(rc, abs(p_.wait()))
+    # wait for all; a rank that dies takes the others down with it (they would sit in a rendezvous or a collective until its
+    # timeout): terminate exactly the processes started here
+    rc, live = 0, list(procs)
+    while live:
+        for p_ in list(live):
+            r = p_.poll()
+            if r is None:
+                continue
+            live.remove(p_)
+            rc = max(rc, abs(r))
+            if r != 0:
+                for q_ in live:
+                    q_.terminate()
+        if live:
+            time.sleep(0.2)
     return rc
 
 
@@ -803,12 +815,22 @@ def tp_leg(qp, torch, dist, args, rank, world, device):
     hidden = max(m.out_features for groups in layers for grp in (groups[1], groups[3]) for m, _, _ in grp) * world
     res = {"workload": f"llama3.1-70b_tcq_6: {nl} layers, row-sharded over {world} ranks ({qstr})", "world": world,
            "backend": args.dist_backend}
-    peer = None
+    def all_ranks_ok(ok):
+        """every rank must take the same branch (the branches contain collectives)"""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t[0]))
+
+    peer, err = None, None
     try:
         peer = qp.shard.PeerGatherer(world, rank, device, max_bytes=16 * hidden * 4 // world + 4096, slots=2 * nl + 2)
+    except Exception as exc:  # (PeerGatherer's set-up collectives have completed or failed on every rank alike)
+        err = repr(exc)
+    if all_ranks_ok(peer is not None):
         res["peer_gather"] = {"flag_memory": peer.flag_memory, "validated_against_collective": bool(peer.validate())}
-    except Exception as exc:
-        res["peer_gather"] = {"error": repr(exc), "validated_against_collective": False}
+    else:
+        res["peer_gather"] = {"error": err or "set-up failed on another rank", "validated_against_collective": False}
+        peer = None
     stream = torch.cuda.Stream(device)
 
     def timed(token, graphable):
@@ -848,7 +870,7 @@ def tp_leg(qp, torch, dist, args, rank, world, device):
             token, _ = make_token(qp, torch, layers, xs, nb, device, launch="multi", gather=peer)
             t = timed(token, True)
             torch.cuda.synchronize()
-            if peer.error() == 0:
+            if all_ranks_ok(peer.error() == 0):
                 fig["peer_gather_in_graph"] = {"tokens_per_s": nb / t, "ms_per_step": t * 1e3}
             else:
                 fig["peer_gather_in_graph"] = {"error": "a peer gather gave up waiting for a flag"}

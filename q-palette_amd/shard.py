@@ -188,6 +188,7 @@ class PeerGatherer:
             for p in self._own:
                 lib.qpal_peer_free(p)
             self._own = []
+        self.bufs = self.ws = None  # views of freed memory
 
     def new_token(self):
         if self._next == 1 and self._sites_last_token == 1:
