@@ -566,7 +566,7 @@ struct TcEarly {
 // host: the launch qualifies when x is staged in LDS and every job has the same x, codebook and batch
 inline TcEarly early_args(const TcMultiParams &mp) {
     const TcParams &a = mp.job[0];
-    // (x and its 32-half zero pad must fit the chunks the threads hold: 16 384 halves per 16-wave workgroup)
+    // (x and its 32-half zero pad must fit the chunks the threads hold)
     TcEarly e{a.x, a.tab, a.n, a.k, a.x_lds && !a.x_rot && a.n <= 8 && a.n * a.k + 32 <= kEarlyXChunks * 64 * gemv_waves<1>() * 8 ? 1 : 0};
     for (int j = 1; j < mp.njobs; j++) {
         const TcParams &b = mp.job[j];
@@ -605,7 +605,11 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
 #ifdef QPAL_CONFLICT_FREE
     constexpr bool kEarly = NBG == 1 && !ROT;
 #else
-    constexpr bool kEarly = NBG == 1 && !ROT && NV * NT <= 4096;  // <= 4 entries per thread of a 16-wave workgroup
+    // <= 4 entries per thread of a 16-wave workgroup.  NOT in the any-KV / mixed-family kernels (round 3): holding the early values
+    // across their seven decode loops' set-up spilled 16-28 VGPRs, and a kernel that touches scratch at all pays ~1 us per
+    // launch — without early staging they have no spills and the q | k | v launch of a mixed-scheme model takes 7.1 instead of
+    // 8.3 us (llama3.1-8b_figure1c 651 -> 707 tok/s, mem3p25 678 -> 722, one box: profiles/r03_ab_any_spills.txt).
+    constexpr bool kEarly = NBG == 1 && !ROT && NV * NT <= 4096 && !is_any_v<C1>;
 #endif
     constexpr int EV = NV < 4 ? NV : 4;  // image entries a thread holds across the argument fetch; the rest are built after it
     constexpr int XR = kEarlyXChunks;    // 16-byte chunks of x a thread holds likewise
