@@ -157,7 +157,9 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
             for (int i = blockIdx.x * NT + tid; i < mp.zero_chunks; i += gridDim.x * NT) mp.zero[i] = u32x4{0u, 0u, 0u, 0u};
         }
         if (p.tab != cur_tab) {  // workgroup-uniform
-            C1::build(lut, p.tab, tid, NT);
+            // (the 128 KiB image is 16 chunks per thread: two batches of 8 table reads instead of 16 dependent round trips)
+            if constexpr (C1::LDS_DWORDS * 4 > 64 * 1024 && NBG <= 4) C1::template build<8>(lut, p.tab, tid, NT);
+            else C1::build(lut, p.tab, tid, NT);
             cur_tab = p.tab;
         }
         store_x(xt);

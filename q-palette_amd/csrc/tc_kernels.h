@@ -129,8 +129,12 @@ __device__ __forceinline__ void build_image(uint32_t *lds, int tid, int nthreads
 // ================================================================================================
 // TCQ codec.  Bit surgery on one lane's KV dwords (reference lanes A = bits [0,16KV), B = [16KV,32KV))
 // for tile group G = ksub*2 + msub; state I in 0..7 (0..3 = lane A's j, 4..7 = lane B's j).
-template <int S, int KV>
+// XS = 1 (S = 9 only): the conflict-free image — 32 copies per entry (128 KiB, one bank per lane of a ds_read_b32 group) addressed
+// through 2h = h + h, a fourth (full-rate) VALU op per pair.  A loss in the batch-1 GEMV, where the VALU is the scarcer pipe
+// (-12 %); used by the lockstep skinny-GEMM kernel up to 4 batch groups, where the LDS is (§4.7).
+template <int S, int KV, int XS_ = 0>
 struct TcqCodec {
+    static_assert(XS_ == 0 || S == 9, "the 32-copy image exists for the 1024-entry codebooks only");
     static constexpr int S_ = S;
     static constexpr int NW = KV;          // dwords per lane per supertile
     static constexpr int L4 = 4 * KV;      // stream bits per reference lane per tile
@@ -141,13 +145,7 @@ struct TcqCodec {
     // then ONE v_and_or_b32: (h & mask) | 4*(lane mod copies).  Lanes l and l+16 of a 32-lane ds_read_b32
     // group share a copy, so half of the gathers are 2-way bank conflicts: LDS has the slack, the
     // half-rate VALU does not (perf/valu_rate.hip).
-    // Experiment (make VARIANT=cf EXTRA=-DQPAL_CONFLICT_FREE, S = 9 only): 32 copies per entry (128 KiB, one bank per lane of a
-    // ds_read_b32 group: no conflicts) addressed through 2h = h + h — a fourth VALU op per pair, full rate.  DESIGN.md §4.9.
-#ifdef QPAL_CONFLICT_FREE
-    static constexpr int XS = S == 9 ? 1 : 0;
-#else
-    static constexpr int XS = 0;
-#endif
+    static constexpr int XS = XS_;
     static constexpr int ROWSHIFT = 15 - S + XS;       // log2(bytes per entry row)
     static constexpr int LOG2C = ROWSHIFT - 2;         // copies per entry
     static constexpr int C = 1 << LOG2C;
@@ -484,11 +482,7 @@ constexpr int gemv_waves() { return NBG >= 4 ? 8 : 16; }
 #endif
 // LDS beside the 64 KiB codebook image: reduction buffer [waves][n][32] fp32 (+ x for batch <= 8)
 template <int NBG>
-#ifdef QPAL_CONFLICT_FREE  // (experiment build: batch 1 only — the wide-batch kernels compile but must not be launched)
-constexpr int scratch_bytes() { return kScratchBytes; }
-#else
 constexpr int scratch_bytes() { return NBG == 1 ? kScratchBytes : gemv_waves<NBG>() * 32 * 4 * 8 * NBG; }
-#endif
 
 // Mixed-precision launches: everything about a TCQ codec except the bit surgery depends on the codebook size S only (the
 // LDS image, its address mask, the hash), so single-stream layers of one S but DIFFERENT KV — q, k and v of a mixed-scheme
@@ -602,15 +596,11 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     // the first weight loads have been issued)
     constexpr int NV = (C1::CHUNKS + NT - 1) / NT;
     // (the 128 KiB images of the wide VQ/SQ codebooks would hold 8 entries per thread: spills, measured 20-30 % slower)
-#ifdef QPAL_CONFLICT_FREE
-    constexpr bool kEarly = NBG == 1 && !ROT;
-#else
     // <= 4 entries per thread of a 16-wave workgroup.  NOT in the any-KV / mixed-family kernels (round 3): holding the early values
     // across their seven decode loops' set-up spilled 16-28 VGPRs, and a kernel that touches scratch at all pays ~1 us per
     // launch — without early staging they have no spills and the q | k | v launch of a mixed-scheme model takes 7.1 instead of
     // 8.3 us (llama3.1-8b_figure1c 651 -> 707 tok/s, mem3p25 678 -> 722, one box: profiles/r03_ab_any_spills.txt).
     constexpr bool kEarly = NBG == 1 && !ROT && NV * NT <= 4096 && !is_any_v<C1>;
-#endif
     constexpr int EV = NV < 4 ? NV : 4;  // image entries a thread holds across the argument fetch; the rest are built after it
     constexpr int XR = kEarlyXChunks;    // 16-byte chunks of x a thread holds likewise
     [[maybe_unused]] u32x4 exr[XR];
