@@ -98,6 +98,8 @@ def parse_args():
                     help="N > 1: skip the `tp_70b` figures (Llama-3.1-70B shapes row-sharded over the N GPUs, batch 1 and 16)")
     ap.add_argument("--tp-layers", type=int, default=0, help="layers of the tp_70b leg (0 = the model's 80)")
     ap.add_argument("--tp-steps", type=int, default=0, help="timed steps of each tp_70b figure (0 = min(--steps, 30))")
+    ap.add_argument("--tp-timeout", type=float, default=float(os.environ.get("QPAL_TP_TIMEOUT", "300")),
+                    help="seconds after which the tp_70b leg is abandoned (the headline line is printed without it)")
     return ap.parse_args()
 
 
@@ -755,12 +757,30 @@ def main():
         # experiment knob (cache-resident weights): NOT the benchmark — say so where the number is read
         out["config"]["INVALID_experiment_knob"] = "QPAL_BENCH_SHARED_WEIGHTS: every layer aliases layer 0's buffers"
         out["metric"] = "EXPERIMENT (shared weights), not the headline metric"
+    printed = [False]
+    watchdog = None
     if world > 1 and not args.no_tp_leg and not tp:
         # BASELINE configs[4]: Llama-3.1-70B shapes @3.0 b row-sharded over the N GPUs, batch 1 and batch 16 (strong scaling),
-        # after the headline's timed region; every rank takes part (collectives), rank 0 reports
+        # after the headline's timed region; every rank takes part (collectives), rank 0 reports.
+        # The headline line must not depend on this leg: a rank that raises leaves the others inside a collective, and a
+        # collective that never completes would take the (already measured) headline with it — so a watchdog bounds the leg
+        # and everything after it: on expiry rank 0 prints the line with the leg marked abandoned, and every rank leaves.
+        import threading
+
+        def abandon():
+            if rank == 0 and not printed[0]:
+                printed[0] = True
+                out["tp_70b"] = {"error": f"abandoned after {args.tp_timeout} s (a rank failed or a collective did not complete); "
+                                          "the headline above was measured before this leg"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.tp_timeout, abandon)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             out["tp_70b"] = tp_leg(qp, torch, dist, args, rank, world, device)
-        except Exception as exc:  # the headline line must not depend on this leg
+        except Exception as exc:
             out["tp_70b"] = {"error": repr(exc)}
     if rank == 0:
         if world == 1 and not args.no_whole_model and not args.incoherent and n == 1:
@@ -774,10 +794,17 @@ def main():
             layers = build_model(qp, torch, model_key, qstr, 1, device, distinct_codebooks=args.distinct_codebooks,
                                  packing=args.packing, keep_infos=True)
             out["cpu_baseline"] = cpu_baseline(qp, layers, n, args.cpu_seconds, nlayers)
-        print(json.dumps(out), flush=True)
+        if not printed[0]:
+            printed[0] = True
+            print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:  # (a rank that failed in the leg above is not at this barrier; the line is out)
+            pass
+    if watchdog is not None:
+        watchdog.cancel()
 
 
 def whole_model_leg(args):

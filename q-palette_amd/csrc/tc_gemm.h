@@ -24,9 +24,77 @@ constexpr int kGemmXGroup = 16 * kGemmXRow;  // one batch group (8 rows x 2 colu
 // geometry of one job (host: plan_gemm): items = ceil(nrows / 8) * sk, item -> (row group, K split)
 //   uses TcParams: nrows, nsc1/2, st1/2, col2, sk, out/ldo, wscale/oscale, accumulate, c1/c2, x, tab, n, k
 
+// Software-pipelined step (QPAL_GEMM_PIPE, default): a wave issues in order, so a decode -> wait for the gathers -> NBG MFMAs
+// sequence per A fragment leaves the matrix pipe idle during the decode and the VALU / LDS idle during the MFMAs, and with two
+// waves per SIMD walking in lockstep nothing else fills the gaps (measured at 8 batch groups: a step took the SUM of its MFMA,
+// LDS and VALU time, 2.2 us).  Here fragment t + 1 (t = 4 ksub + 2 msub + jl) is decoded BETWEEN the MFMAs of fragment t — the
+// order is pinned with sched_barrier fences, one weight pair in front of each of the first MFMAs, the rest of the MFMAs cover
+// the gather latency — and the B fragments of ksub 1 replace those of ksub 0 one batch group at a time behind their last use.
+#ifndef QPAL_GEMM_PIPE
+#define QPAL_GEMM_PIPE 1
+#endif
+// Timing experiments only (results invalid): QPAL_GEMM_KO bit 1: no MFMAs (operands xor-folded), 2: no B-fragment reads, 4: no x
+// staging inside the loop, 8: no per-step barrier, 32: no weight loads inside the loop; -DQPAL_KO_GATHER: no codebook gathers.
+#ifndef QPAL_GEMM_BUILD_U
+#define QPAL_GEMM_BUILD_U 1
+#endif
+#ifndef QPAL_GEMM_KO
+#define QPAL_GEMM_KO 0
+#endif
+template <class Codec, int T, int I>
+__device__ __forceinline__ uint32_t gemm_pair(const uint32_t *lut, uint32_t laneoff, const uint32_t (&w)[Codec::NW]) {
+    constexpr int g = T >> 1, jl = T & 1;
+    constexpr int idx[4] = {jl, jl + 4, jl + 2, jl + 6};  // fragment order (jh, isB): i = jl + 2 jh + 4 isB
+    uint32_t nh = 0u;
+    if constexpr (Codec::kNeedsNext) nh = row16_next(Codec::template head<g>(w));  // (one per g: CSE)
+    return Codec::template pair<g, idx[I]>(lut, laneoff, w, nh);
+}
+
+template <class Codec, int NBG>
+__device__ __forceinline__ void gemm_step_pipe(const uint32_t *lut, uint32_t laneoff, const uint32_t (&w)[Codec::NW],
+                                               const unsigned char *xt, int lane, Acc<NBG> &acc) {
+    const unsigned char *xl = xt + (lane & 15) * kGemmXRow + (lane >> 4) * 32;
+    u32x4 xb[NBG];
+    static_for<0, NBG>([&](auto bc) {
+        if constexpr (QPAL_GEMM_KO & 2) xb[decltype(bc)::value] = u32x4{laneoff, (uint32_t)lane, laneoff, (uint32_t)lane};
+        else xb[decltype(bc)::value] = *reinterpret_cast<const u32x4 *>(xl + decltype(bc)::value * kGemmXGroup);
+    });
+    uint32_t a[4], an[4];
+    static_for<0, 4>([&](auto ic) { a[decltype(ic)::value] = gemm_pair<Codec, 0, decltype(ic)::value>(lut, laneoff, w); });
+    // pairs of the next fragment decoded in front of MFMA m of this one: all four in front of the first half of the MFMAs
+    constexpr int PER = NBG >= 8 ? 1 : NBG >= 4 ? 2 : 4;  // pairs per slot
+    static_for<0, 8>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int ksub = t >> 2, msub = (t >> 1) & 1, jl = t & 1;
+        static_for<0, NBG>([&](auto bc) {
+            constexpr int m = decltype(bc)::value;
+            if constexpr (t < 7 && m * PER < 4) {
+                static_for<0, PER>([&](auto ic) {
+                    constexpr int i = m * PER + decltype(ic)::value;
+                    an[i] = gemm_pair<Codec, t + 1, i>(lut, laneoff, w);
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (QPAL_GEMM_KO & 1) {
+                if constexpr (m == 0 || t == 0 || t == 4) {
+                    const uint32_t f = m == 0 ? a[0] ^ a[1] ^ a[2] ^ a[3] : 0u;
+                    const uint32_t fx = (t == 0 || t == 4) ? xb[m].x ^ xb[m].y ^ xb[m].z ^ xb[m].w : 0u;
+                    acc.v[m][msub * 2 + jl][0] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, acc.v[m][msub * 2 + jl][0]) ^ f ^ fx);
+                }
+            } else
+            acc.v[m][msub * 2 + jl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                __builtin_bit_cast(half8_t, u32x4{a[0], a[1], a[2], a[3]}), __builtin_bit_cast(half8_t, xb[m]), acc.v[m][msub * 2 + jl], 0, 0, 0);
+            if constexpr (t == 3 && !(QPAL_GEMM_KO & 2)) xb[m] = *reinterpret_cast<const u32x4 *>(xl + m * kGemmXGroup + 16);  // ksub 1, behind the last use of ksub 0
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<0, 4>([&](auto ic) { a[decltype(ic)::value] = an[decltype(ic)::value]; });
+    });
+}
+
 template <class Codec, int NBG>
 __device__ __forceinline__ void gemm_step(const uint32_t *lut, uint32_t laneoff, const uint32_t (&w)[Codec::NW],
                                           const unsigned char *xt, int lane, Acc<NBG> &acc) {
+    if constexpr (QPAL_GEMM_PIPE != 0) return gemm_step_pipe<Codec, NBG>(lut, laneoff, w, xt, lane, acc);
     const unsigned char *xl = xt + (lane & 15) * kGemmXRow + (lane >> 4) * 32;
     static_for<0, 2>([&](auto kc) {
         constexpr int ksub = decltype(kc)::value;
@@ -159,7 +227,7 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
         if (p.tab != cur_tab) {  // workgroup-uniform
             // (the 128 KiB image is 16 chunks per thread: two batches of 8 table reads instead of 16 dependent round trips)
             if constexpr (C1::LDS_DWORDS * 4 > 64 * 1024 && NBG <= 4) C1::template build<8>(lut, p.tab, tid, NT);
-            else C1::build(lut, p.tab, tid, NT);
+            else C1::template build<QPAL_GEMM_BUILD_U>(lut, p.tab, tid, NT);
             cur_tab = p.tab;
         }
         store_x(xt);
@@ -175,14 +243,17 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
             using CC = typename decltype(codec_c)::type;
             for (int g = ga; g < gb; g++) {
                 const int gn = g + 1 < g1 ? g + 1 : g;
-                load_w(gn, wnext);
-                load_x(gn);
+                if constexpr (QPAL_GEMM_KO & 32) {
+#pragma unroll
+                    for (int i = 0; i < NWMAX; i++) wnext[i] = wcur[i] + 1;
+                } else load_w(gn, wnext);
+                if constexpr (!(QPAL_GEMM_KO & 4)) load_x(gn);
                 __builtin_amdgcn_sched_barrier(0);
                 const int par = (g - g0) & 1;
                 if (live)  // (wave-uniform: a row past the end of the layer only keeps the staging and the barriers company)
                     gemm_step<CC, NBG>(lut, laneoff, reinterpret_cast<uint32_t(&)[CC::NW]>(wcur), xt + par * XBUF, lane, acc);
-                store_x(xt + (par ^ 1) * XBUF);  // last read before the previous barrier
-                __syncthreads();
+                if constexpr (!(QPAL_GEMM_KO & 4)) store_x(xt + (par ^ 1) * XBUF);  // last read before the previous barrier
+                if constexpr (!(QPAL_GEMM_KO & 8)) __syncthreads();
 #pragma unroll
                 for (int i = 0; i < NWMAX; i++) wcur[i] = wnext[i];
             }
@@ -199,8 +270,11 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
         // D[4 q + r][cidx]; valid where (r & 1) == u: on even lanes own r = 0 / 2 plus the odd neighbour's r = 1 / 3 are tile rows
         // 8 a + 2 q + {0, 1}.  One batch group at a time goes through a per-wave [8][32] fp32 scratch and leaves as 128-byte runs.
         float *scr = reinterpret_cast<float *>(xt) + wave * 256;
-        const int q = lane >> 4, cidx = lane & 15;
-        const int r32 = lane & 31;
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));  // the epilogue's addresses are computed HERE: hoisted out of the item loop they sat in
+                                          // registers through the steps (1 spilled VGPR at 8 batch groups = scratch set-up per launch)
+        const int q = lane_e >> 4, cidx = lane_e & 15;
+        const int r32 = lane_e & 31;
         float osc = p.oscale;
         if (p.wscale && live) osc *= (float)__builtin_bit_cast(_Float16, p.wscale[sr * 32 + r32]);
         auto epilogue = [&](auto mode_c) {
@@ -217,7 +291,7 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
                 // (wave-private scratch: LDS operations of one wave complete in order)
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const int bl = 2 * i + (lane >> 5), b = 8 * grp + bl;
+                    const int bl = 2 * i + (lane_e >> 5), b = 8 * grp + bl;
                     const float v = scr[bl * 32 + r32] * osc;
                     if (live && b < p.n) {
                         float *dst = p.out + (long)b * p.ldo + (long)sr * 32 + r32;

@@ -236,7 +236,11 @@ struct TcqCodec {
         asm("v_mad_u32_u24 %0, %1, %1, %1" : "=v"(h) : "v"(s));  // s*s + s: low 16 bits exact
         if constexpr (XS == 1) asm("v_add_u32 %0, %1, %1" : "=v"(h) : "v"(h));  // (h << 1 as a shift is a half-rate op)
         const uint32_t a = (h & HMASK) | laneoff;
+#ifdef QPAL_KO_GATHER  // timing experiment (tc_gemm.h): the address instead of the gathered entry
+        return a;
+#else
         return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + a);
+#endif
     }
 };
 

@@ -99,3 +99,21 @@ def test_gpus_2_rehearsed_on_one_gpu_through_the_spawn_path():
     for key in ("bs1", "bs16"):
         fig = tp[key]
         assert fig["value"] > 0 and "tokens_per_s" in fig["collective_eager"] and "tokens_per_s" in fig["peer_gather_in_graph"]
+
+
+@pytest.mark.gpu
+def test_headline_line_survives_an_abandoned_tp_leg():
+    """The tp_70b leg runs after the headline's timed region and contains collectives: if it cannot complete (a rank fails, a
+    collective hangs) the watchdog must still get rank 0's ONE line out, with the leg marked as an error, and exit code 0."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--force-device", "0", "--dist-backend", "gloo",
+           "--steps", "4", "--warmup", "1", "--layers", "2", "--tp-layers", "2", "--no-kind-breakdown", "--tp-timeout", "0.05"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "error" in d["tp_70b"]
