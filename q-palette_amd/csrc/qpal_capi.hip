@@ -229,6 +229,49 @@ void plan_gemm(TcMultiParams &mp, int &grid) {
     grid = total < kNumCU ? total : kNumCU;
 }
 
+// Few-row launches at a wide batch (lockstep kernel): the chip is filled by splitting K, and every split adds m * n * 4 bytes of
+// float atomics (o / down of Llama-8B at batch 64: 16 row groups -> K split 4 / 8, 64 / 128 of 256 CUs busy, the atomics 13 % of a
+// token).  Slices of the BATCH are independent instead — no reduction at all, the decode (cheap beside 8 batch groups of MFMAs
+// and B-fragment reads) repeated per slice: the launch runs them as jobs of their own (same weights, x and out moved by the
+// slice's first row), then K is split as before.  Returns the rows of the widest slice.  QPAL_GEMM_BS=<n> forces n slices.
+int slice_gemm_batch(TcMultiParams &mp, int *ms, int *zeroed) {
+    static const int force = env_int("QPAL_GEMM_BS", 0);
+    static const int min_rows = env_int("QPAL_GEMM_BS_MIN_ROWS", 16);
+    static const int want_items = env_int("QPAL_GEMM_ITEMS", 192);
+    const int n = mp.job[0].n;
+    int groups = 0;
+    for (int j = 0; j < mp.njobs; j++) groups += (mp.job[j].nrows + kGemmWaves - 1) / kGemmWaves;
+    // measured (Llama-8B tcomb_6_7, tokens/s without -> with, profiles/r03_gemm_batch_slices.txt): two slices of the few-row launches
+    // (q|k|v, o, down) 64: 17 500 -> 18 870, 32: 13 270 -> 13 440; FOUR slices (16 rows each at 64) 17 650, slicing gate|up as well
+    // 18 490, slices of 8 rows -9...-14 %: at most two, never below 16 rows
+    int bs = 1;
+    while (bs < (force > 0 ? force : 2) && mp.njobs * bs * 2 <= kMaxJobs && n / (bs * 2) >= min_rows &&
+           (force > 0 || groups * bs * 2 <= want_items))
+        bs *= 2;
+    if (bs == 1) return n;
+    const int rows = ((n + bs - 1) / bs + 7) & ~7;  // whole batch groups per slice
+    const TcMultiParams src = mp;
+    int ms0[kMaxJobs], z0[kMaxJobs];
+    for (int j = 0; j < kMaxJobs; j++) {
+        ms0[j] = ms[j];
+        z0[j] = zeroed[j];
+    }
+    int nj = 0;
+    for (int j = 0; j < src.njobs; j++)
+        for (int b0 = 0; b0 < n; b0 += rows) {
+            TcParams q = src.job[j];
+            q.n = n - b0 < rows ? n - b0 : rows;
+            q.x = q.x + (long)b0 * q.k;
+            q.out = q.out + (long)b0 * q.ldo;
+            mp.job[nj] = q;
+            ms[nj] = ms0[j];
+            zeroed[nj] = z0[j];
+            nj++;
+        }
+    mp.njobs = nj;
+    return rows;
+}
+
 // batches 9..64: which kernel.  QPAL_GEMM=0: the per-wave-K-chunk kernel (tc_gemv_kernel, x from L2 per wave);
 // 1 (default): the lockstep kernel with the step's activations shared through LDS (tc_gemm.h)
 bool use_gemm(int nbg, const TcMultiParams &mp) {
@@ -388,10 +431,12 @@ int tcq_gemv_one(float *out, long ldo, const void *c1, const void *c2, const voi
     int grid;
     const int nbg = nbg_of(n);
     if (use_gemm(nbg, mp)) {
+        int ms[kMaxJobs] = {m}, zeroed[kMaxJobs] = {0};
+        const int rows = slice_gemm_batch(mp, ms, zeroed);
         plan_gemm(mp, grid);
-        int rc = zero_if_split(mp.job[0], m, stream);
+        int rc = zero_split_jobs(mp, ms, zeroed, stream);
         if (rc) return rc;
-        return launch_tcq_gemm(mp, S, KV1, KV2, nbg, grid, stream);
+        return launch_tcq_gemm(mp, S, KV1, KV2, nbg_of(rows), grid, stream);
     }
     plan_launch(mp, nullptr, grid, waves_of(nbg));
     int rc = zero_if_split(mp.job[0], m, stream);
@@ -501,9 +546,19 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         for (int j = 0; j < njobs; j++)
             if (jobs[j].x_had) return QPAL_E_SHAPE;  // fused rotation: batch 1
     const bool gemm = !mixed && use_gemm(nbg, mp);
-    if (gemm) plan_gemm(mp, grid);
-    else plan_launch(mp, zeroed, grid, waves_of(nbg));
     int ms[kMaxJobs] = {0};
+    if (gemm) {
+        for (int j = 0; j < njobs; j++) {
+            ms[j] = jobs[j].m;
+            zeroed[j] = jobs[j].out_zeroed;
+        }
+        const int rows = slice_gemm_batch(mp, ms, zeroed);
+        plan_gemm(mp, grid);
+        int rc = zero_split_jobs(mp, ms, zeroed, s);
+        if (rc) return rc;
+        return launch_tcq_gemm(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, nbg_of(rows), grid, s);
+    }
+    plan_launch(mp, zeroed, grid, waves_of(nbg));
     for (int j = 0; j < njobs; j++) {
         ms[j] = jobs[j].m;
         zeroed[j] = jobs[j].out_zeroed;
@@ -514,7 +569,6 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         int rc = zero_split_jobs(mp, ms, zeroed, s);
         if (rc) return rc;
     }
-    if (gemm) return launch_tcq_gemm(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, nbg, grid, s);
     if (mixed) return launch_tcq_gemv_any(mp, S, grid, s);
     return launch_tcq_gemv(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, nbg, grid, s);
 }
@@ -628,9 +682,19 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
     // the reduction buffer of 8 batch groups (64 KiB) does not fit beside a 128 KiB codebook image
     if (nbg == 8 && lut_image_bytes(bits, vec) > 64 * 1024) return QPAL_E_SHAPE;
     const bool gemm = use_gemm(nbg, mp);
-    if (gemm) plan_gemm(mp, grid);
-    else plan_launch(mp, zeroed, grid, waves_of(nbg));
     int ms[kMaxJobs] = {0};
+    if (gemm) {
+        for (int j = 0; j < njobs; j++) {
+            ms[j] = jobs[j].m;
+            zeroed[j] = jobs[j].out_zeroed;
+        }
+        const int rows = slice_gemm_batch(mp, ms, zeroed);
+        plan_gemm(mp, grid);
+        int rc = zero_split_jobs(mp, ms, zeroed, s);
+        if (rc) return rc;
+        return launch_lut_tc_gemm(mp, bits, vec, nbg_of(rows), grid, s);
+    }
+    plan_launch(mp, zeroed, grid, waves_of(nbg));
     for (int j = 0; j < njobs; j++) {
         ms[j] = jobs[j].m;
         zeroed[j] = jobs[j].out_zeroed;
@@ -640,7 +704,6 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
         int rc = zero_split_jobs(mp, ms, zeroed, s);
         if (rc) return rc;
     }
-    if (gemm) return launch_lut_tc_gemm(mp, bits, vec, nbg, grid, s);
     return launch_lut_tc_gemv(mp, bits, vec, nbg, grid, s);
 }
 

@@ -34,7 +34,7 @@ constexpr int kGemmXGroup = 16 * kGemmXRow;  // one batch group (8 rows x 2 colu
 #define QPAL_GEMM_PIPE 1
 #endif
 // Timing experiments only (results invalid): QPAL_GEMM_KO bit 1: no MFMAs (operands xor-folded), 2: no B-fragment reads, 4: no x
-// staging inside the loop, 8: no per-step barrier, 32: no weight loads inside the loop; -DQPAL_KO_GATHER: no codebook gathers.
+// staging inside the loop, 8: no per-step barrier, 32: no weight loads inside the loop, 64: no output stores / atomics, 128: no codebook image build; -DQPAL_KO_GATHER: no codebook gathers.
 #ifndef QPAL_GEMM_BUILD_U
 #define QPAL_GEMM_BUILD_U 1
 #endif
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
         if (gitem == (int)blockIdx.x && mp.zero_chunks > 0) {  // pre-zero a buffer for a later split-K launch on this stream
             for (int i = blockIdx.x * NT + tid; i < mp.zero_chunks; i += gridDim.x * NT) mp.zero[i] = u32x4{0u, 0u, 0u, 0u};
         }
-        if (p.tab != cur_tab) {  // workgroup-uniform
+        if (p.tab != cur_tab && (!(QPAL_GEMM_KO & 128) || p.n == 12345)) {  // workgroup-uniform
             // (the 128 KiB image is 16 chunks per thread: two batches of 8 table reads instead of 16 dependent round trips)
             if constexpr (C1::LDS_DWORDS * 4 > 64 * 1024 && NBG <= 4) C1::template build<8>(lut, p.tab, tid, NT);
             else C1::template build<QPAL_GEMM_BUILD_U>(lut, p.tab, tid, NT);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
                 for (int i = 0; i < 4; i++) {
                     const int bl = 2 * i + (lane_e >> 5), b = 8 * grp + bl;
                     const float v = scr[bl * 32 + r32] * osc;
-                    if (live && b < p.n) {
+                    if (live && b < p.n && (!(QPAL_GEMM_KO & 64) || v == 12345.678f)) {
                         float *dst = p.out + (long)b * p.ldo + (long)sr * 32 + r32;
                         if constexpr (mode == 2) atomicAdd(dst, v);
                         else if constexpr (mode == 1) *dst += v;
