@@ -391,13 +391,30 @@ def test_fused_skinny_gemm_batch_9_to_64(qp, oracle, qstr, k, m):
     assert layer.max_fused_batch == (32 if qstr.startswith("ldlq_2_12") else 64)
     W = _oracle_weight(oracle, qstr, info, m, k)
     gen = torch.Generator().manual_seed(9)
-    for n in (9, 13, 16, 17, 31, 32, 33, 64):
+    for n in (9, 13, 16, 17, 31, 32, 33, 37, 50, 64):  # (from 32 on a few-row launch runs as two slices of the batch: 37 = 24 + 13)
         if n > layer.max_fused_batch:
             continue
         x = torch.randn(n, k, generator=gen).half()
         y = layer(x.cuda().float())
         assert y.dtype == torch.float32 and tuple(y.shape) == (n, m)
         _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle)
+
+
+def test_batch_slices_of_a_multi_job_launch(qp, oracle):
+    """q | k | v at a wide batch: the lockstep kernel's launch carries every projection twice, once per slice of the batch
+    (csrc/qpal_capi.hip slice_gemm_batch: 3 jobs -> 6), each slice writing its own rows of the [n, m] outputs."""
+    k, qstr = 4096, "tcomb_6_7_0.5_none_0.9"
+    infos = [qp.mem_op.dummy_linear_info(k, m, qstr, seed=40 + i, codebook_seed=11) for i, m in enumerate((1024, 256, 256))]
+    mods = [qp.make_linear_from_info(qstr, info).cuda() for info in infos]
+    qp.share_codebooks(mods)
+    Ws = [_oracle_weight(oracle, qstr, info, m, k) for info, m in zip(infos, (1024, 256, 256))]
+    gen = torch.Generator().manual_seed(12)
+    for n in (32, 40, 64):
+        x = torch.randn(n, k, generator=gen).half()
+        ys = qp.multi_gemv(mods, x.cuda())
+        for y, W, m in zip(ys, Ws, (1024, 256, 256)):
+            assert tuple(y.shape) == (n, m)
+            _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle)
 
 
 def test_mixed_kv_projections_share_one_launch(qp, oracle):
