@@ -204,9 +204,14 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves 
 // range together; K is split over workgroups (float atomics into a zeroed output) only while the launch has too few row groups
 // to occupy the chip and every split keeps >= kGemmMinSteps steps.  QPAL_GEMM_SK=<n> forces the split (experiments).
 constexpr int kGemmMinSteps = 4;
-void plan_gemm(TcMultiParams &mp, int &grid) {
+// two_per_cu: one batch group beside a 64 KiB codebook image (75 KiB of LDS, < 128 VGPRs): two workgroups share a CU — 4 waves per
+// SIMD hide each other's barrier waits — and the launch is planned for twice the items (batch 4 / 8: +3 % tokens/s, measured).
+void plan_gemm(TcMultiParams &mp, int &grid, bool two_per_cu = false) {
     static const int force_sk = env_int("QPAL_GEMM_SK", 0);
-    static const int want_items = env_int("QPAL_GEMM_ITEMS", 192);  // measured: 96 / 192 / 256 / 512 -> 4.9 / 4.1 / 4.5 / 5.3 ms per Llama-8B step at batch 64
+    static const int items_env = env_int("QPAL_GEMM_ITEMS", 0);  // measured: 96 / 192 / 256 / 512 -> 4.9 / 4.1 / 4.5 / 5.3 ms per Llama-8B step at batch 64
+    static const int mult_env = env_int("QPAL_GEMM_GRID_MULT", 0);
+    const int grid_mult = mult_env > 0 ? mult_env : (two_per_cu ? 2 : 1);
+    const int want_items = items_env > 0 ? items_env : 192 * grid_mult;
     static const int min_steps = env_int("QPAL_GEMM_MINSTEPS", kGemmMinSteps);
     int groups = 0;
     for (int j = 0; j < mp.njobs; j++) groups += (mp.job[j].nrows + kGemmWaves - 1) / kGemmWaves;
@@ -226,7 +231,7 @@ void plan_gemm(TcMultiParams &mp, int &grid) {
         mp.item_end[j] = total;
     }
     mp.total_items = total;
-    grid = total < kNumCU ? total : kNumCU;
+    grid = total < kNumCU * grid_mult ? total : kNumCU * grid_mult;
 }
 
 // Few-row launches at a wide batch (lockstep kernel): the chip is filled by splitting K, and every split adds m * n * 4 bytes of
@@ -433,7 +438,7 @@ int tcq_gemv_one(float *out, long ldo, const void *c1, const void *c2, const voi
     if (use_gemm(nbg, mp)) {
         int ms[kMaxJobs] = {m}, zeroed[kMaxJobs] = {0};
         const int rows = slice_gemm_batch(mp, ms, zeroed);
-        plan_gemm(mp, grid);
+        plan_gemm(mp, grid, nbg_of(rows) == 1 && S == 9);
         int rc = zero_split_jobs(mp, ms, zeroed, stream);
         if (rc) return rc;
         return launch_tcq_gemm(mp, S, KV1, KV2, nbg_of(rows), grid, stream);
@@ -553,7 +558,7 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
             zeroed[j] = jobs[j].out_zeroed;
         }
         const int rows = slice_gemm_batch(mp, ms, zeroed);
-        plan_gemm(mp, grid);
+        plan_gemm(mp, grid, nbg_of(rows) == 1 && S == 9);
         int rc = zero_split_jobs(mp, ms, zeroed, s);
         if (rc) return rc;
         return launch_tcq_gemm(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, nbg_of(rows), grid, s);
@@ -689,7 +694,7 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
             zeroed[j] = jobs[j].out_zeroed;
         }
         const int rows = slice_gemm_batch(mp, ms, zeroed);
-        plan_gemm(mp, grid);
+        plan_gemm(mp, grid, nbg_of(rows) == 1 && lut_image_bytes(bits, vec) <= 64 * 1024);
         int rc = zero_split_jobs(mp, ms, zeroed, s);
         if (rc) return rc;
         return launch_lut_tc_gemm(mp, bits, vec, nbg_of(rows), grid, s);

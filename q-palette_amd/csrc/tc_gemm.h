@@ -35,6 +35,9 @@ constexpr int kGemmXGroup = 16 * kGemmXRow;  // one batch group (8 rows x 2 colu
 #endif
 // Timing experiments only (results invalid): QPAL_GEMM_KO bit 1: no MFMAs (operands xor-folded), 2: no B-fragment reads, 4: no x
 // staging inside the loop, 8: no per-step barrier, 32: no weight loads inside the loop, 64: no output stores / atomics, 128: no codebook image build; -DQPAL_KO_GATHER: no codebook gathers.
+#ifndef QPAL_GEMM_SLOTS
+#define QPAL_GEMM_SLOTS 4
+#endif
 #ifndef QPAL_GEMM_BUILD_U
 #define QPAL_GEMM_BUILD_U 1
 #endif
@@ -149,7 +152,11 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
     constexpr int NCH = NBG * 8 * 16;                   // 16-byte chunks of one step's x tile
     constexpr int CPT = (NCH + NT - 1) / NT;            // chunks per thread
     constexpr int NWMAX = C1::NW > CB::NW ? C1::NW : CB::NW;
-    constexpr int XT = 2 * XBUF >= W * 1024 ? 2 * XBUF : W * 1024;  // the x buffers double as the epilogue's per-wave transposition scratch
+    // Tile slots: 4 where they fit beside the codebook image (two steps per buffer: the workgroup barrier — 9 % of a batch-64 token
+    // as a per-step barrier, knock-out 8 — falls after every SECOND step, tiles are staged two steps ahead), else 2 (one per step)
+    constexpr int NSLOT = (QPAL_GEMM_SLOTS == 4 && C1::LDS_DWORDS * 4 + 4 * XBUF <= 156 * 1024) ? 4 : 2;
+    constexpr int AHEAD = NSLOT / 2;
+    constexpr int XT = NSLOT * XBUF >= W * 1024 ? NSLOT * XBUF : W * 1024;  // the x buffers double as the epilogue's per-wave transposition scratch
     __shared__ __attribute__((aligned(16))) uint32_t lut[C1::LDS_DWORDS];
     __shared__ __attribute__((aligned(16))) unsigned char xt[XT];
 
@@ -221,6 +228,12 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
 
         load_w(g0, wcur);
         load_x(g0);
+        [[maybe_unused]] u32x4 xr1[CPT];  // (4 slots: the second step's tile, requested together with the first)
+        if constexpr (AHEAD == 2) {
+#pragma unroll
+            for (int r = 0; r < CPT; r++) xr1[r] = xr[r];
+            load_x(g0 + 1 < g1 ? g0 + 1 : g0);
+        }
         if (gitem == (int)blockIdx.x && mp.zero_chunks > 0) {  // pre-zero a buffer for a later split-K launch on this stream
             for (int i = blockIdx.x * NT + tid; i < mp.zero_chunks; i += gridDim.x * NT) mp.zero[i] = u32x4{0u, 0u, 0u, 0u};
         }
@@ -229,6 +242,11 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
             if constexpr (C1::LDS_DWORDS * 4 > 64 * 1024 && NBG <= 4) C1::template build<8>(lut, p.tab, tid, NT);
             else C1::template build<QPAL_GEMM_BUILD_U>(lut, p.tab, tid, NT);
             cur_tab = p.tab;
+        }
+        if constexpr (AHEAD == 2) {
+            store_x(xt + XBUF);
+#pragma unroll
+            for (int r = 0; r < CPT; r++) xr[r] = xr1[r];
         }
         store_x(xt);
         Acc<NBG> acc;
@@ -247,13 +265,16 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
 #pragma unroll
                     for (int i = 0; i < NWMAX; i++) wnext[i] = wcur[i] + 1;
                 } else load_w(gn, wnext);
-                if constexpr (!(QPAL_GEMM_KO & 4)) load_x(gn);
+                if constexpr (!(QPAL_GEMM_KO & 4)) load_x(g + AHEAD < g1 ? g + AHEAD : g1 - 1);
                 __builtin_amdgcn_sched_barrier(0);
-                const int par = (g - g0) & 1;
+                const int i = g - g0;
                 if (live)  // (wave-uniform: a row past the end of the layer only keeps the staging and the barriers company)
-                    gemm_step<CC, NBG>(lut, laneoff, reinterpret_cast<uint32_t(&)[CC::NW]>(wcur), xt + par * XBUF, lane, acc);
-                if constexpr (!(QPAL_GEMM_KO & 4)) store_x(xt + (par ^ 1) * XBUF);  // last read before the previous barrier
-                if constexpr (!(QPAL_GEMM_KO & 8)) __syncthreads();
+                    gemm_step<CC, NBG>(lut, laneoff, reinterpret_cast<uint32_t(&)[CC::NW]>(wcur), xt + (i & (NSLOT - 1)) * XBUF, lane, acc);
+                // slot of step i + AHEAD: last read AHEAD steps ago, i.e. before the latest barrier
+                if constexpr (!(QPAL_GEMM_KO & 4)) store_x(xt + ((i + AHEAD) & (NSLOT - 1)) * XBUF);
+                if constexpr (!(QPAL_GEMM_KO & 8)) {
+                    if (AHEAD == 1 || (i & 1)) __syncthreads();
+                }
 #pragma unroll
                 for (int i = 0; i < NWMAX; i++) wcur[i] = wnext[i];
             }
@@ -266,6 +287,7 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
             }
         }
 
+        if constexpr (AHEAD == 2) __syncthreads();  // (an odd number of steps ends without one: the scratch below overlays the tiles)
         // ---- epilogue: lane (q = lane >> 4, cidx = lane & 15 = 2 b' + u) holds, for batch row 8 grp + b' and a = msub * 2 + jl,
         // D[4 q + r][cidx]; valid where (r & 1) == u: on even lanes own r = 0 / 2 plus the odd neighbour's r = 1 / 3 are tile rows
         // 8 a + 2 q + {0, 1}.  One batch group at a time goes through a per-wave [8][32] fp32 scratch and leaves as 128-byte runs.
