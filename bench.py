@@ -294,6 +294,25 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
             outs += views
         return outs
 
+    # Batch 1..3, multi-job launches: the harness owns the outputs here too — one block per launch, zeroed by the launch before it
+    # (prezero), so that the library may share rows between workgroups (pair mode) or split K wherever that fills the chip,
+    # without a memset node of its own.  The first launch of a token has no predecessor: its outputs are not declared zeroed.
+    owned = None
+    if launch in ("multi", "chain") and gather is None and parts is None and not batched and not no_prezero and \
+            all(n <= m.max_fused_batch and type(m) in qp.linear._PACKED_KEYS for groups in layers for grp in groups for m, _, _ in grp):
+        owned = []
+        for groups in layers:
+            per = []
+            for grp in groups:
+                ms = [m.out_features for m, _, _ in grp]
+                flat = torch.empty(n * sum(ms), dtype=torch.float32, device=device)
+                views, off = [], 0
+                for m_ in ms:
+                    views.append(flat[off: off + n * m_].view(n, m_))
+                    off += n * m_
+                per.append((flat, views))
+            owned.append(per)
+
     def token():
         if parts is not None:
             return token_chain()
@@ -302,9 +321,16 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
         outs = []
         if hasattr(gather, "new_token"):
             gather.new_token()  # the same call sites take the same peer-gather slots in every (captured) token
-        for groups in layers:
+        for li, groups in enumerate(layers):
             pre = {}  # group index -> output buffer zeroed by an earlier launch of this block
             for gi, grp in enumerate(groups):
+                if owned is not None:
+                    flat, views = owned[li][gi]
+                    nli, ngi = (li, gi + 1) if gi < 3 else (li + 1, 0)
+                    nxt = owned[nli][ngi][0] if nli < len(layers) else None
+                    if only_kind is None or only_kind == gi:
+                        outs += qp.multi_gemv([m for m, _, _ in grp], xs[grp[0][1]], outs=views, outs_zeroed=(li, gi) != (0, 0), prezero=nxt)
+                    continue
                 x = xs[grp[0][1]]
                 mods = [m for m, _, _ in grp]
                 if gather is not None and launch in ("multi", "chain") and n <= min(m.max_fused_batch for m in mods):

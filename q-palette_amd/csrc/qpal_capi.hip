@@ -156,7 +156,7 @@ int items_at(const TcMultiParams &mp, int log2_wpr, int waves = 16) {
 }
 
 // out_zeroed[j]: the caller pre-zeroed job j's output (split-K is then free of a memset node)
-void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves = 16) {
+void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves = 16, bool allow_pair = false) {
     static const int force_sk = env_int("QPAL_FORCE_SK", 0);
     static const int force_wpr = env_int("QPAL_FORCE_WPR", -1);
     int min_st = 1 << 30;
@@ -190,6 +190,26 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves 
         }
         if (force_sk > 0) sk = force_sk;
         set_chunks(p, log2_wpr, sk, waves);
+    }
+    // Pair mode (TcParams::pair): 4 or 2 rows per workgroup, nothing split, every output zeroed (or accumulated onto) and the
+    // launch still one round: two workgroups share the last of their rows — 2 R - 1 rows per pair instead of 2 R, every SIMD
+    // with 3.5 / 4 (R = 4) or 3 / 4 (R = 2) of the steps.  QPAL_PAIR=0 switches it off (A/B).
+    static const int pair_on = env_int("QPAL_PAIR", 1);
+    const int R = waves >> log2_wpr;
+    bool pair = allow_pair && pair_on && waves == 16 && (R == 4 || R == 2) && !pairs && force_sk <= 0 && out_zeroed != nullptr;
+    int pair_items = 0;
+    for (int j = 0; j < mp.njobs && pair; j++) {
+        const TcParams &p = mp.job[j];
+        pair = p.sk == 1 && (out_zeroed[j] || p.accumulate) && p.rem1 == 0 && p.rem2 == 0 && p.base1 >= 2 && (p.base1 & 1) == 0 &&
+               (p.base2 & 1) == 0 && (p.st2 == 0 || p.base2 >= 2);
+        pair_items += 2 * ((p.nrows + 2 * R - 2) / (2 * R - 1));
+    }
+    if (pair && pair_items <= cap && pair_items > items) {
+        for (int j = 0; j < mp.njobs; j++) {
+            TcParams &p = mp.job[j];
+            p.sk = -1;
+            p.nitems = 2 * ((p.nrows + 2 * R - 2) / (2 * R - 1));
+        }
     }
     int total = 0;
     for (int j = 0; j < kMaxJobs; j++) {
@@ -563,7 +583,9 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         if (rc) return rc;
         return launch_tcq_gemm(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, nbg_of(rows), grid, s);
     }
-    plan_launch(mp, zeroed, grid, waves_of(nbg));
+    bool plain = !mixed && nbg == 1;  // pair mode: the plain TCQ kernels of one batch group have a pair-aware twin (tcq_gemv_pair.hip)
+    for (int j = 0; j < njobs; j++) plain = plain && !mp.job[j].x_rot;
+    plan_launch(mp, zeroed, grid, waves_of(nbg), plain);
     for (int j = 0; j < njobs; j++) {
         ms[j] = jobs[j].m;
         zeroed[j] = jobs[j].out_zeroed;

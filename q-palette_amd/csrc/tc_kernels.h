@@ -54,6 +54,14 @@ struct TcParams {
     int x_lds;          // 1: stage x[n][k] in LDS (fits beside the codebook image)
     int base1, rem1;    // stream 1: st1 = nc1*base1 + rem1 (first rem1 chunks get one more step)
     int base2, rem2;    // stream 2: st2 = (nchunk-nc1)*base2 + rem2
+    // pair mode (tc_gemv_kernel, plan_launch): workgroups 2 i and 2 i + 1 own 2 R - 1 supertile rows (R = rows per workgroup): R - 1
+    // whole rows each in their first R - 1 row slots, and the LAST slot of both is the same row, its K range halved between them
+    // (atomics into a zeroed output) — 3.5 instead of 4 rows per CU: a layer of 896 rows (gate | up of Llama-8B) runs on 256
+    // instead of 224 CUs, every SIMD with 28 instead of 32 steps.  *_s: the chunk partition of the shared slot (2 wpr chunks).
+    // Encoded as sk == -1, with NO fields of its own: the kernel is at its SGPR limit (6 more dwords of job made the compiler spill
+    // the preloaded arguments and wait for the kernel-argument block three times: -5 % tokens/s with pair mode off).  The planner
+    // uses it only where the chunk partition halves exactly: rem1 == rem2 == 0, base1 and base2 even — the shared slot then has
+    // 2 nc1 stream-1 chunks of base1 / 2 steps (and base2 / 2 on stream 2).
     int kv;                  // TcqAny kernels only: this job's KV (trellis dwords per lane)
     int kv2;                 // TcqAny kernels only: KV of stream 2 of a column-split (combt) job, 0: single stream
     int lut_bits, lut_vec;   // TcqMix kernels only: != 0: this job is a VQ/SQ (LutCodec<lut_bits, lut_vec>) layer; kv = its dwords per lane
@@ -574,7 +582,7 @@ inline TcEarly early_args(const TcMultiParams &mp) {
 }
 
 // ROT: 0 plain; 1: can rotate x while staging it (k = 2048 / 4096, wht64.h); 2: the 14336-wide rotation of rot_k28.h (its own
-// instantiation: its registers would make the other rotating launches spill)
+// instantiation: its registers would make the other rotating launches spill); 3: plain + pair mode (TcParams: sk == -1)
 template <class C1, class C2, int NBG, int ROT = 0>
 __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const void *etab, int en, int ek, int eon,
                                                        const TcMultiParams mp) {
@@ -604,7 +612,8 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     // across their seven decode loops' set-up spilled 16-28 VGPRs, and a kernel that touches scratch at all pays ~1 us per
     // launch — without early staging they have no spills and the q | k | v launch of a mixed-scheme model takes 7.1 instead of
     // 8.3 us (llama3.1-8b_figure1c 651 -> 707 tok/s, mem3p25 678 -> 722, one box: profiles/r03_ab_any_spills.txt).
-    constexpr bool kEarly = NBG == 1 && !ROT && NV * NT <= 4096 && !is_any_v<C1>;
+    constexpr bool PAIRK = ROT == 3;  // plain kernel that also understands pair-mode jobs (sk == -1, TcParams)
+    constexpr bool kEarly = NBG == 1 && (ROT == 0 || ROT == 3) && NV * NT <= 4096 && !is_any_v<C1>;
     constexpr int EV = NV < 4 ? NV : 4;  // image entries a thread holds across the argument fetch; the rest are built after it
     constexpr int XR = kEarlyXChunks;    // 16-byte chunks of x a thread holds likewise
     [[maybe_unused]] u32x4 exr[XR];
@@ -665,23 +674,43 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
             rg = item / p.sk;
             ks = item - rg * p.sk;
         }
-        const int sr = (rg << log2_rpw) + rloc;
+        // row slot rl of this workgroup -> supertile row (pair mode: sk == -1, see TcParams); everything recomputed where it is
+        // used rather than kept in SGPRs across the steps
+        // (ROT == 3 kernels only — the same code in every plain kernel cost them 2.4 % with pair mode off: SGPRs.  Branch-free:
+        // slot rl < last -> row_base + rl, the last slot -> row_last; sk == -1: rg is the item)
+        [[maybe_unused]] const int slot_last = (1 << log2_rpw) - 1;
+        int row_base = rg << log2_rpw;
+        [[maybe_unused]] int row_last = row_base + slot_last;
+        bool shared = false;  // wave-uniform
+        if constexpr (PAIRK) {
+            if (p.sk < 0) {
+                row_base = (rg >> 1) * (2 * slot_last + 1) + ((rg & 1) << log2_rpw);
+                row_last = (rg >> 1) * (2 * slot_last + 1) + slot_last;
+                shared = rloc == slot_last;
+            }
+        }
+        auto row_of = [&](int rl) {
+            if constexpr (PAIRK) return rl == slot_last ? row_last : row_base + rl;
+            else return row_base + rl;
+        };
+        const int sr = row_of(rloc);
         const bool live = sr < p.nrows;
         // per-row output scale of the epilogue: requested now, consumed after the steps (a load issued there
         // would put a whole memory round trip at the end of the kernel)
         uint32_t wraw;
         asm volatile("" : "=v"(wraw));  // "no value yet": a constant here would be merged with the load at the join
                                         // below, and the merge waits for the load on the spot
-        if (p.wscale && tid < (32 << log2_rpw) && (rg << log2_rpw) + (tid >> 5) < p.nrows)
-            wraw = p.wscale[((rg << log2_rpw) + (tid >> 5)) * 32 + (tid & 31)];
-        const int c = ks * wpr + wr;
+        if (p.wscale && tid < (32 << log2_rpw) && row_of(tid >> 5) < p.nrows)
+            wraw = p.wscale[row_of(tid >> 5) * 32 + (tid & 31)];
+        const int c = (shared ? (rg & 1) : ks) * wpr + wr;
         // chunk c -> (stream, [s0, s1)): chunk j of a stream covers base steps, the first rem chunks one more
         // (any-KV kernels take column-split jobs too: the two streams are two KV of the same codebook size, and the waves of a
         // row pick their decode loop by the stream their chunk lies in — a wave-uniform choice)
         constexpr bool ANY = is_any_v<C1>;
-        const bool on2 = (TWO || (ANY && p.kv2 != 0)) && c >= p.nc1;
-        const int cc = on2 ? c - p.nc1 : c;
-        const int base = on2 ? p.base2 : p.base1, rem = on2 ? p.rem2 : p.rem1;
+        const int nc1 = shared ? 2 * p.nc1 : p.nc1;
+        const bool on2 = (TWO || (ANY && p.kv2 != 0)) && c >= nc1;
+        const int cc = on2 ? c - nc1 : c;
+        const int base = (on2 ? p.base2 : p.base1) >> (shared ? 1 : 0), rem = on2 ? p.rem2 : p.rem1;  // (pair mode: rem == 0)
         int s0 = cc * base + (cc < rem ? cc : rem);
         int s1 = s0 + base + (cc < rem ? 1 : 0);
         if (!live) s0 = s1 = 0;
@@ -931,7 +960,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         QPAL_STAMP(6);
         if (tid < (32 << log2_rpw)) {
             const int r = tid & 31, rl = tid >> 5;
-            const int srow = (rg << log2_rpw) + rl;
+            const int srow = row_of(rl);
             [[maybe_unused]] bool continue_item = false;
             if (srow < p.nrows) {
                 // the incoherent wrappers' `* Wscale * scale`, fused
@@ -957,7 +986,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                     for (int qq = 0; qq < wpr; qq++) v += red[(((rl << p.log2_wpr) + qq) * p.n + b) * 32 + r];
                     float *dst = p.out + (long)b * p.ldo + (long)srow * 32 + r;
                     v *= osc;
-                    if (p.sk > 1) atomicAdd(dst, v);
+                    if (p.sk > 1 || (PAIRK && p.sk < 0 && rl == slot_last)) atomicAdd(dst, v);
                     else if (p.accumulate) *dst += v;  // the residual add of a decoder block: out is the fp32 residual stream
                     else *dst = v;
                 }
