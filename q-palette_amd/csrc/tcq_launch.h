@@ -51,7 +51,7 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
                 prev = cur;
             }
         }
-        printf("[stamps] %s grid %d m %d k %d wpr %d sk %d: first stamp -> last stamp %.2f us (wave starts spread over %.2f us, wave ends over %.2f us); mean / max per-wave phase (us):", ROT ? "ROT" : "plain", grid,
+        printf("[stamps] %s grid %d m %d k %d wpr %d sk %d: first stamp -> last stamp %.2f us (wave starts spread over %.2f us, wave ends over %.2f us); mean / max per-wave phase (us):", ROT == 3 ? "pair" : ROT ? "ROT" : "plain", grid,
                p.nrows * 32, p.k, 1 << p.log2_wpr, p.sk, (t7 - t0) / 100.0, (t0max - t0) / 100.0, (t7 - t7min) / 100.0);
         const char *nm[8] = {"", "issue-w", "x+lut", "barrier", "steps", "xor-red", "barrier2", "final"};
         for (int i = 1; i < 8; i++) printf(" %s %.2f/%.2f", nm[i], ph[i] / (nw ? nw : 1) / 100.0, phmax[i] / 100.0);
