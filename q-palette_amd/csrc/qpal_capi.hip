@@ -1,5 +1,6 @@
 // C-ABI entry points (include/qpal.h): argument checks, launch geometry, dispatch.  No allocation, no
 // synchronisation, everything on the caller's stream (graph-capturable).
+#include <stdio.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdlib.h>
@@ -218,6 +219,14 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves 
     }
     mp.total_items = total;
     grid = total < cap ? total : cap;
+    static const int plan_log = env_int("QPAL_PLAN_LOG", 0);  // one line per planned GEMV launch on stderr (tests, debugging)
+    if (plan_log) {
+        fprintf(stderr, "[qpal plan] gemv: %d jobs, grid %d, waves per row %d:", mp.njobs, grid, 1 << log2_wpr);
+        for (int j = 0; j < mp.njobs; j++)
+            fprintf(stderr, " [rows %d steps %d+%d %s items %d]", mp.job[j].nrows, mp.job[j].st1, mp.job[j].st2,
+                    mp.job[j].sk < 0 ? "pair" : mp.job[j].sk > 1 ? "split-K" : "whole rows", mp.job[j].nitems);
+        fprintf(stderr, "\n");
+    }
 }
 
 // Geometry of the lockstep skinny-GEMM kernel (tc_gemm.h, batch > 8): a workgroup = 8 waves = 8 supertile rows that walk one K

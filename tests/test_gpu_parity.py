@@ -7,6 +7,7 @@ oracle's float64 sum: |err| <= 1e-5 * sum_k |w_k x_k| (k <= 28672; fp32 unit rou
 sqrt(k)-to-k growth factor), with fp16-output kernels (SIMT family) adding one fp16 rounding.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -682,3 +683,50 @@ def test_llama70b_row_shard_of_8(qp, oracle, kind, rank):
         (y,) = qp.multi_gemv([layer], x.cuda())
         assert y.dtype == torch.float32 and tuple(y.shape) == (n, ms)
         _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle)
+
+
+@pytest.mark.parametrize("qstr,m", [("tcomb_6_7_0.5_none_0.9", 8960), ("tcq_6_none_0.9", 8960), ("tcq_5_none_0.9", 5120)])
+def test_pair_mode_rows_shared_by_two_workgroups(qp, oracle, qstr, m):
+    """Pair mode of the GEMV planner (csrc/tc_kernels.h TcParams, qpal_capi.hip plan_launch): two projections of one input whose
+    outputs the caller declares zeroed — 2 x 280 rows at 4 rows per workgroup pair up as 7 rows per two workgroups (160 items
+    instead of 140), 2 x 160 rows at 2 rows per workgroup as 3 per two; the shared row's halves meet by atomics.  Against the
+    oracle, against the unpaired launch of the same layers, bit-identical between repeats, and with accumulate."""
+    import subprocess, textwrap
+    k = 4096
+    infos = [qp.mem_op.dummy_linear_info(k, m, qstr, seed=70 + i, codebook_seed=13) for i in range(2)]
+    mods = [qp.make_linear_from_info(qstr, info).cuda() for info in infos]
+    qp.share_codebooks(mods)
+    Ws = [_oracle_weight(oracle, qstr, info, m, k) for info in infos]
+    gen = torch.Generator().manual_seed(21)
+    for n in (1, 3):
+        x = torch.randn(n, k, generator=gen).half()
+        plain = qp.multi_gemv(mods, x.cuda())
+        outs = [torch.zeros(n, m, dtype=torch.float32, device="cuda") for _ in mods]
+        got = qp.multi_gemv(mods, x.cuda(), outs=outs, outs_zeroed=True)
+        again = qp.multi_gemv(mods, x.cuda(), outs=[torch.zeros_like(o) for o in outs], outs_zeroed=True)
+        for y, y2, p_, W in zip(got, again, plain, Ws):
+            _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle)
+            assert torch.equal(y, y2)  # two adders per element: order-independent
+            assert torch.allclose(y, p_, rtol=1e-4, atol=1e-4 * float(p_.abs().max()))
+        res = [torch.randn(n, m, generator=gen).cuda() for _ in mods]
+        acc = [r.clone() for r in res]
+        qp.multi_gemv(mods, x.cuda(), outs=acc, accumulate=True)
+        for a, r, p_ in zip(acc, res, plain):
+            assert torch.allclose(a, r + p_, rtol=1e-4, atol=1e-4 * float(p_.abs().max()))
+    # the planner really paired these launches (its log line says so), and QPAL_PAIR=0 does not
+    code = textwrap.dedent(f"""
+        import torch, qpalette_amd as qp
+        infos = [qp.mem_op.dummy_linear_info({k}, {m}, "{qstr}", seed=70 + i, codebook_seed=13) for i in range(2)]
+        mods = [qp.make_linear_from_info("{qstr}", info).cuda() for info in infos]
+        qp.share_codebooks(mods)
+        x = torch.randn(1, {k}).half().cuda()
+        qp.multi_gemv(mods, x, outs=[torch.zeros(1, {m}, device="cuda") for _ in mods], outs_zeroed=True)
+        torch.cuda.synchronize()
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for pair, want in (("1", True), ("0", False)):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, QPAL_PLAN_LOG="1", QPAL_PAIR=pair, PYTHONPATH=root),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        lines = [l for l in r.stderr.splitlines() if l.startswith("[qpal plan]")]
+        assert lines and (" pair " in lines[-1]) == want, lines
