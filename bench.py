@@ -298,7 +298,7 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
     # (prezero), so that the library may share rows between workgroups (pair mode) or split K wherever that fills the chip,
     # without a memset node of its own.  The first launch of a token has no predecessor: its outputs are not declared zeroed.
     owned = None
-    if launch in ("multi", "chain") and gather is None and parts is None and not batched and not no_prezero and \
+    if launch in ("multi", "chain") and parts is None and not batched and not no_prezero and \
             all(n <= m.max_fused_batch and type(m) in qp.linear._PACKED_KEYS for groups in layers for grp in groups for m, _, _ in grp):
         owned = []
         for groups in layers:
@@ -329,7 +329,12 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
                     nli, ngi = (li, gi + 1) if gi < 3 else (li + 1, 0)
                     nxt = owned[nli][ngi][0] if nli < len(layers) else None
                     if only_kind is None or only_kind == gi:
-                        outs += qp.multi_gemv([m for m, _, _ in grp], xs[grp[0][1]], outs=views, outs_zeroed=(li, gi) != (0, 0), prezero=nxt)
+                        ys = qp.multi_gemv([m for m, _, _ in grp], xs[grp[0][1]], outs=views, outs_zeroed=(li, gi) != (0, 0), prezero=nxt)
+                        # row-sharded model (--parallel tp, tp_70b): the outputs of o_proj / down_proj feed full-width consumers
+                        # (the next block's rotation): all-gather them.  q|k|v stay head-sharded through attention, gate|up
+                        # channel-sharded into down_proj.  A shard has 1 / N of the rows: with its outputs owned
+                        # and zeroed the planner can split K until the chip is busy, without memset nodes.
+                        outs += [gather(y) for y in ys] if gather is not None and gi in (1, 3) else ys
                     continue
                 x = xs[grp[0][1]]
                 mods = [m for m, _, _ in grp]
@@ -896,20 +901,23 @@ def tp_leg(qp, torch, dist, args, rank, world, device):
                 with torch.cuda.graph(g, stream=stream):
                     token()
                 run = g.replay
-            for _ in range(3):
+            # (the eager collective token is the checked baseline, 160 library collectives per step: a few steps are enough,
+            # and the whole leg has to fit its watchdog also where the ranks share one card)
+            nsteps = steps if graphable else min(steps, 5)
+            for _ in range(3 if graphable else 1):
                 run()
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(steps):
+            for _ in range(nsteps):
                 run()
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t[0]) / steps
+            return float(t[0]) / nsteps
 
     for nb in (1, 16):
         xs = {}
