@@ -866,6 +866,12 @@ def tp_leg(qp, torch, dist, args, rank, world, device):
     batch 1 and batch 16, each with the one-shot peer-write gather inside a HIP graph — but only after PeerGatherer.validate()
     has agreed with the library collective on this node — and with dist.all_gather_into_tensor (RCCL) between eager launches
     as the checked baseline.  value = the faster VALID one."""
+    t_leg = time.perf_counter()
+
+    def log(msg):  # progress on stderr (rank 0): where a slow or abandoned leg spent its time
+        if rank == 0:
+            print(f"[bench tp_70b +{time.perf_counter() - t_leg:6.1f} s] {msg}", file=sys.stderr, flush=True)
+
     model_key, qstr = WORKLOADS["llama3.1-70b_tcq_6"]
     nl = args.tp_layers or qp.mem_op.get_layer_info(model_key)["nlayers"]
     steps = args.tp_steps or max(5, min(args.steps, 30))
@@ -879,6 +885,7 @@ def tp_leg(qp, torch, dist, args, rank, world, device):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(int(t[0]))
 
+    log(f"{nl} layers of this rank's shard built")
     peer, err = None, None
     try:
         peer = qp.shard.PeerGatherer(world, rank, device, max_bytes=16 * hidden * 4 // world + 4096, slots=2 * nl + 2)
@@ -889,6 +896,7 @@ def tp_leg(qp, torch, dist, args, rank, world, device):
     else:
         res["peer_gather"] = {"error": err or "set-up failed on another rank", "validated_against_collective": False}
         peer = None
+    log(f"peer gather: {res['peer_gather']}")
     stream = torch.cuda.Stream(device)
 
     def timed(token, graphable):
@@ -931,6 +939,7 @@ def tp_leg(qp, torch, dist, args, rank, world, device):
             token, _ = make_token(qp, torch, layers, xs, nb, device, launch="multi", gather=peer)
             t = timed(token, True)
             torch.cuda.synchronize()
+            log(f"batch {nb}: peer gather in graph {t * 1e3:.2f} ms per step")
             if all_ranks_ok(peer.error() == 0):
                 fig["peer_gather_in_graph"] = {"tokens_per_s": nb / t, "ms_per_step": t * 1e3}
             else:
@@ -939,6 +948,7 @@ def tp_leg(qp, torch, dist, args, rank, world, device):
         coll = qp.shard.make_gatherer(world, device)
         token, _ = make_token(qp, torch, layers, xs, nb, device, launch="multi", gather=coll)
         t = timed(token, False)
+        log(f"batch {nb}: collective between eager launches {t * 1e3:.2f} ms per step")
         fig["collective_eager"] = {"tokens_per_s": nb / t, "ms_per_step": t * 1e3}
         valid = [v for v in fig.values() if "tokens_per_s" in v]
         best = max(valid, key=lambda v: v["tokens_per_s"])
