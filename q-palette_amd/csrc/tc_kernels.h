@@ -116,6 +116,9 @@ struct TcMultiParams {
 #ifndef QPAL_BUILD_U
 #define QPAL_BUILD_U 1
 #endif
+#ifndef QPAL_ROT_BUILD_U  // the image build of the rotating kernels' builder waves (12 of 16 at k = 4096) only
+#define QPAL_ROT_BUILD_U 1
+#endif
 constexpr int kBuildInFlight = QPAL_BUILD_U;
 template <int CHUNKS, int LOG2C, int U, class Entry>
 __device__ __forceinline__ void build_image(uint32_t *lds, int tid, int nthreads, Entry &&entry) {
@@ -851,7 +854,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                         if (lane == 0) part[wave] = ss;
                     }
                     if (p.tab != cur_tab) {
-                        if (wave >= p.x_rot) C1::build(lut, p.tab, tid - 64 * p.x_rot, 1024 - 64 * p.x_rot);
+                        if (wave >= p.x_rot) C1::template build<QPAL_ROT_BUILD_U>(lut, p.tab, tid - 64 * p.x_rot, 1024 - 64 * p.x_rot);
                         cur_tab = p.tab;
                     }
                     if (tid < 32) xs[total + tid] = 0;
