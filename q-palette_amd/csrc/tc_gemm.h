@@ -5,7 +5,7 @@
 // [n][128] slice of x per step from L2 (16 KiB per wave-step at n = 64) and waits for it — at batch 64 the step was bound by
 // that round trip, not by the decode or the matrix pipe (7.7 ms per Llama-8B step: 0.05 of the MFMA roofline).  Here the 8
 // waves of a workgroup own 8 DIFFERENT supertile rows and walk the SAME K range in lockstep: the [n][128] tile of x of a step
-// is loaded ONCE per workgroup, one step ahead (global -> registers -> LDS, double-buffered, one barrier per step), in the
+// is loaded ONCE per workgroup, two steps ahead (global -> registers -> LDS, four tile slots, one barrier per two steps), in the
 // layout the MFMA B fragments are read in (one ds_read_b128 per batch group and ksub).  A wave sees its whole K range, so
 // there is no cross-wave reduction; split-K over workgroups (atomics) only where a layer has too few rows to fill the chip.
 //
@@ -24,12 +24,13 @@ constexpr int kGemmXGroup = 16 * kGemmXRow;  // one batch group (8 rows x 2 colu
 // geometry of one job (host: plan_gemm): items = ceil(nrows / 8) * sk, item -> (row group, K split)
 //   uses TcParams: nrows, nsc1/2, st1/2, col2, sk, out/ldo, wscale/oscale, accumulate, c1/c2, x, tab, n, k
 
-// Software-pipelined step (QPAL_GEMM_PIPE, default): a wave issues in order, so a decode -> wait for the gathers -> NBG MFMAs
-// sequence per A fragment leaves the matrix pipe idle during the decode and the VALU / LDS idle during the MFMAs, and with two
-// waves per SIMD walking in lockstep nothing else fills the gaps (measured at 8 batch groups: a step took the SUM of its MFMA,
-// LDS and VALU time, 2.2 us).  Here fragment t + 1 (t = 4 ksub + 2 msub + jl) is decoded BETWEEN the MFMAs of fragment t — the
-// order is pinned with sched_barrier fences, one weight pair in front of each of the first MFMAs, the rest of the MFMAs cover
-// the gather latency — and the B fragments of ksub 1 replace those of ksub 0 one batch group at a time behind their last use.
+// Software-pipelined step (QPAL_GEMM_PIPE, default): a wave issues in order, and the compiler's own order per A fragment is
+// decode -> wait for the gathers -> NBG MFMAs, which leaves the matrix pipe idle during the decode and the VALU / LDS idle during
+// the MFMAs unless the SIMD's other wave fills the gaps.  Here fragment t + 1 (t = 4 ksub + 2 msub + jl) is decoded BETWEEN the
+// MFMAs of fragment t — the order is pinned with sched_barrier fences, one weight pair in front of each of the first MFMAs, the
+// rest of the MFMAs cover the gather latency — and the B fragments of ksub 1 replace those of ksub 0 one batch group at a time
+// behind their last use.  Measured: +-0.5 % at every batch (profiles/r03_gemm_knockouts.txt) — the two waves of a SIMD did
+// overlap each other's phases; what a step loses is the lockstep wait at the barrier.
 #ifndef QPAL_GEMM_PIPE
 #define QPAL_GEMM_PIPE 1
 #endif
@@ -68,7 +69,7 @@ __device__ __forceinline__ void gemm_step_pipe(const uint32_t *lut, uint32_t lan
     constexpr int PER = NBG >= 8 ? 1 : NBG >= 4 ? 2 : 4;  // pairs per slot
     static_for<0, 8>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        constexpr int ksub = t >> 2, msub = (t >> 1) & 1, jl = t & 1;
+        constexpr int msub = (t >> 1) & 1, jl = t & 1;
         static_for<0, NBG>([&](auto bc) {
             constexpr int m = decltype(bc)::value;
             if constexpr (t < 7 && m * PER < 4) {
