@@ -710,6 +710,10 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         // nothing: tcq_6 +0.6 %, ldlq_1_4 -0.7 %, 70B +-0 (profiles/r03_ab_interleave_rem.txt).  That launch streams 23.9 MB in a
         // ~5 us steps phase = 4.8 TB/s: its steps phase is HBM-bound as much as decode-bound)
         const int c = (shared ? (rg & 1) : ks) * wpr + wr;
+        // chunk c -> (stream, [s0, s1)): chunk j of a stream covers base steps, the first rem chunks one more
+        // (any-KV kernels take column-split jobs too: the two streams are two KV of the same codebook size, and the waves of a
+        // row pick their decode loop by the stream their chunk lies in — a wave-uniform choice)
+        constexpr bool ANY = is_any_v<C1>;
         const int nc1 = shared ? 2 * p.nc1 : p.nc1;
         const bool on2 = (TWO || (ANY && p.kv2 != 0)) && c >= nc1;
         const int cc = on2 ? c - nc1 : c;
