@@ -109,13 +109,17 @@ def spawn_ranks(n):
     them and pass rank 0's output (the ONE JSON line) through.  Nothing is re-exec'ed: the parent stays a plain Python process."""
     import socket
     import subprocess
+    import tempfile
 
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
+    # rank 0 parks the measured headline line here before it enters the tp_70b leg and removes the file once it has printed:
+    # should the leg take the process down (a fault the in-process watchdog cannot catch), the parent prints the parked line
+    park = os.path.join(tempfile.gettempdir(), f"qpal_bench_headline_{os.getpid()}.json")
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), QPAL_BENCH_HEADLINE_FILE=park,
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
@@ -134,6 +138,15 @@ def spawn_ranks(n):
                     q_.terminate()
         if live:
             time.sleep(0.2)
+    if os.path.exists(park):
+        try:
+            with open(park) as f:
+                out = json.load(f)
+            out["tp_70b"] = {"error": f"a rank died inside the leg (exit code {rc}); the headline above was measured before it"}
+            print(json.dumps(out), flush=True)
+            rc = 0
+        finally:
+            os.remove(park)
     return rc
 
 
@@ -804,8 +817,14 @@ def main():
                 out["tp_70b"] = {"error": f"abandoned after {args.tp_timeout} s (a rank failed or a collective did not complete); "
                                           "the headline above was measured before this leg"}
                 print(json.dumps(out), flush=True)
+                if os.environ.get("QPAL_BENCH_HEADLINE_FILE") and os.path.exists(os.environ["QPAL_BENCH_HEADLINE_FILE"]):
+                    os.remove(os.environ["QPAL_BENCH_HEADLINE_FILE"])
             os._exit(0)
 
+        park = os.environ.get("QPAL_BENCH_HEADLINE_FILE") if rank == 0 else None
+        if park:
+            with open(park, "w") as f:
+                json.dump(out, f)
         watchdog = threading.Timer(args.tp_timeout, abandon)
         watchdog.daemon = True
         watchdog.start()
@@ -828,6 +847,9 @@ def main():
         if not printed[0]:
             printed[0] = True
             print(json.dumps(out), flush=True)
+            park = os.environ.get("QPAL_BENCH_HEADLINE_FILE")
+            if park and os.path.exists(park):
+                os.remove(park)
     if world > 1:
         try:
             dist.barrier()

@@ -69,7 +69,20 @@ def test_gpus_n_without_a_launcher_spawns_the_ranks(tmp_path, monkeypatch):
     # a failing rank fails the whole run
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--fail"])
     assert bench.spawn_ranks(2) == 3
+    # a rank 0 that parked its headline and then died inside the tp leg: the parent prints the parked line, marked, rc 0
+    probe.write_text(
+        "import json, os, sys\n"
+        "if os.environ['RANK'] == '0':\n"
+        "    json.dump({'metric': 'm', 'value': 1.5}, open(os.environ['QPAL_BENCH_HEADLINE_FILE'], 'w'))\n"
+        "    os._exit(9)\n")
+    import io, contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = bench.spawn_ranks(2)
+    line = json.loads(buf.getvalue().strip().splitlines()[-1])
+    assert rc == 0 and line["value"] == 1.5 and "died inside the leg" in line["tp_70b"]["error"]
     # and main() takes that path only when no launcher set WORLD_SIZE
+    probe.write_text("import sys\nsys.exit(0)\n")
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
     with pytest.raises(SystemExit) as exc:
         bench.main()
