@@ -730,7 +730,9 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
         if (rc) return rc;
         return launch_lut_tc_gemm(mp, bits, vec, nbg_of(rows), grid, s);
     }
-    plan_launch(mp, zeroed, grid, waves_of(nbg));
+    bool plain = nbg == 1;  // pair mode: lut_gemv_pair.hip
+    for (int j = 0; j < njobs; j++) plain = plain && !mp.job[j].x_rot;
+    plan_launch(mp, zeroed, grid, waves_of(nbg), plain);
     for (int j = 0; j < njobs; j++) {
         ms[j] = jobs[j].m;
         zeroed[j] = jobs[j].out_zeroed;

@@ -685,7 +685,8 @@ def test_llama70b_row_shard_of_8(qp, oracle, kind, rank):
         _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle)
 
 
-@pytest.mark.parametrize("qstr,m", [("tcomb_6_7_0.5_none_0.9", 8960), ("tcq_6_none_0.9", 8960), ("tcq_5_none_0.9", 5120)])
+@pytest.mark.parametrize("qstr,m", [("tcomb_6_7_0.5_none_0.9", 8960), ("tcq_6_none_0.9", 8960), ("tcq_5_none_0.9", 5120),
+                                    ("ldlq_1_4_none_1.0", 8960), ("ldlq_2_9_none_1.0", 5120)])
 def test_pair_mode_rows_shared_by_two_workgroups(qp, oracle, qstr, m):
     """Pair mode of the GEMV planner (csrc/tc_kernels.h TcParams, qpal_capi.hip plan_launch): two projections of one input whose
     outputs the caller declares zeroed — 2 x 280 rows at 4 rows per workgroup pair up as 7 rows per two workgroups (160 items
