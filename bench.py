@@ -773,6 +773,9 @@ def main():
                                                                    else "all-gather (torch.distributed)") if tp else f"dp{world} replicas"),
                    "linears_per_token": nlinear, "launches_per_token": nlaunch, "phases_per_token": nphase,
                    "launch_mode": args.launch,
+                   "outputs": ("fresh per launch (--no-prezero): the library adds a memset node where it splits K" if args.no_prezero else
+                               "owned by the harness, every launch zeroes the next launch's block (the library may split K / pair "
+                               "workgroups without memset nodes; QPAL_PAIR=" + os.environ.get("QPAL_PAIR", "1") + ")"),
                    "incoherent": bool(args.incoherent),
                    "rotation_launches_per_token": nrot[0] if args.incoherent else 0},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
