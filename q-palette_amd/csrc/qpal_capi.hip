@@ -193,23 +193,24 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves 
         set_chunks(p, log2_wpr, sk, waves);
     }
     // Pair mode (TcParams::pair): 4 or 2 rows per workgroup, nothing split, every output zeroed (or accumulated onto) and the
-    // launch still one round: two workgroups share the last of their rows — 2 R - 1 rows per pair instead of 2 R, every SIMD
-    // with 3.5 / 4 (R = 4) or 3 / 4 (R = 2) of the steps.  QPAL_PAIR=0 switches it off (A/B).
+    // launch still one round: two workgroups share the last S of their rows — 2 R - S rows per pair instead of 2 R, every SIMD
+    // with 3.5 / 4 (4, 2 or 1 waves per row) or 3 / 4 (8 waves per row) of the steps.  QPAL_PAIR=0 switches it off (A/B).
     static const int pair_on = env_int("QPAL_PAIR", 1);
     const int R = waves >> log2_wpr;
-    bool pair = allow_pair && pair_on && waves == 16 && (R == 4 || R == 2) && !pairs && force_sk <= 0 && out_zeroed != nullptr;
+    const int pair_rows = 2 * R - pair_shared_slots(log2_wpr);  // rows of a workgroup pair
+    bool pair = allow_pair && pair_on && waves == 16 && R >= 2 && !pairs && force_sk <= 0 && out_zeroed != nullptr;
     int pair_items = 0;
     for (int j = 0; j < mp.njobs && pair; j++) {
         const TcParams &p = mp.job[j];
         pair = p.sk == 1 && (out_zeroed[j] || p.accumulate) && p.rem1 == 0 && p.rem2 == 0 && p.base1 >= 2 && (p.base1 & 1) == 0 &&
                (p.base2 & 1) == 0 && (p.st2 == 0 || p.base2 >= 2);
-        pair_items += 2 * ((p.nrows + 2 * R - 2) / (2 * R - 1));
+        pair_items += 2 * ((p.nrows + pair_rows - 1) / pair_rows);
     }
     if (pair && pair_items <= cap && pair_items > items) {
         for (int j = 0; j < mp.njobs; j++) {
             TcParams &p = mp.job[j];
             p.sk = -1;
-            p.nitems = 2 * ((p.nrows + 2 * R - 2) / (2 * R - 1));
+            p.nitems = 2 * ((p.nrows + pair_rows - 1) / pair_rows);
         }
     }
     int total = 0;

@@ -54,10 +54,11 @@ struct TcParams {
     int x_lds;          // 1: stage x[n][k] in LDS (fits beside the codebook image)
     int base1, rem1;    // stream 1: st1 = nc1*base1 + rem1 (first rem1 chunks get one more step)
     int base2, rem2;    // stream 2: st2 = (nchunk-nc1)*base2 + rem2
-    // pair mode (tc_gemv_kernel, plan_launch): workgroups 2 i and 2 i + 1 own 2 R - 1 supertile rows (R = rows per workgroup): R - 1
-    // whole rows each in their first R - 1 row slots, and the LAST slot of both is the same row, its K range halved between them
-    // (atomics into a zeroed output) — 3.5 instead of 4 rows per CU: a layer of 896 rows (gate | up of Llama-8B) runs on 256
-    // instead of 224 CUs, every SIMD with 28 instead of 32 steps.  *_s: the chunk partition of the shared slot (2 wpr chunks).
+    // pair mode (tc_gemv_kernel, plan_launch): workgroups 2 i and 2 i + 1 own 2 R - S supertile rows (R = rows per workgroup,
+    // S = pair_shared_slots(): as many of the last row slots as it takes to put one of their waves on every SIMD — 1 at 4 or 8 waves
+    // per row, 2 at 2, 4 at 1): R - S whole rows each in their first row slots, and the last S slots of both are the same S rows,
+    // their K ranges halved between the two (atomics into a zeroed output) — every SIMD does 3.5 instead of 4 rows' worth (3 of 4
+    // at R = 2): a layer of 896 rows (gate | up of Llama-8B, R = 4; of Llama-70B, R = 8) runs on 256 instead of 224 CUs.
     // Encoded as sk == -1, with NO fields of its own: the kernel is at its SGPR limit (6 more dwords of job made the compiler spill
     // the preloaded arguments and wait for the kernel-argument block three times: -5 % tokens/s with pair mode off).  The planner
     // uses it only where the chunk partition halves exactly: rem1 == rem2 == 0, base1 and base2 even — the shared slot then has
@@ -88,6 +89,9 @@ struct TcParams {
     uint16_t *act_out;       // ROT kernels, batch 1: the layer's supertile rows alternate up / gate (u0 g0 u1 g1 ...): the epilogue
                              // writes fp16 silu(gate) * up [m / 2] here instead of `out` (rows per workgroup >= 2, no split-K)
 };
+
+// pair mode: row slots of a workgroup that it shares with its partner (host and device)
+__host__ __device__ inline int pair_shared_slots(int log2_wpr) { return log2_wpr >= 2 ? 1 : 4 >> log2_wpr; }
 
 constexpr int kMaxJobs = 8;
 
@@ -681,19 +685,21 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         // used rather than kept in SGPRs across the steps
         // (ROT == 3 kernels only — the same code in every plain kernel cost them 2.4 % with pair mode off: SGPRs.  Branch-free:
         // slot rl < last -> row_base + rl, the last slot -> row_last; sk == -1: rg is the item)
-        [[maybe_unused]] const int slot_last = (1 << log2_rpw) - 1;
+        // whole slots rl < wholes -> row_base + rl; shared slots -> row_shared + rl (one form for both modes: wholes = R, no pair)
         int row_base = rg << log2_rpw;
-        [[maybe_unused]] int row_last = row_base + slot_last;
+        [[maybe_unused]] int wholes = 1 << log2_rpw, row_shared = 0;
         bool shared = false;  // wave-uniform
         if constexpr (PAIRK) {
             if (p.sk < 0) {
-                row_base = (rg >> 1) * (2 * slot_last + 1) + ((rg & 1) << log2_rpw);
-                row_last = (rg >> 1) * (2 * slot_last + 1) + slot_last;
-                shared = rloc == slot_last;
+                wholes = (1 << log2_rpw) - pair_shared_slots(p.log2_wpr);
+                const int pair_rows = (1 << log2_rpw) + wholes;
+                row_base = (rg >> 1) * pair_rows + (rg & 1) * wholes;
+                row_shared = (rg >> 1) * pair_rows + wholes;  // + rl: rows 2 wholes ... of the pair
+                shared = rloc >= wholes;
             }
         }
         auto row_of = [&](int rl) {
-            if constexpr (PAIRK) return rl == slot_last ? row_last : row_base + rl;
+            if constexpr (PAIRK) return rl >= wholes ? row_shared + rl : row_base + rl;
             else return row_base + rl;
         };
         const int sr = row_of(rloc);
@@ -993,7 +999,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                     for (int qq = 0; qq < wpr; qq++) v += red[(((rl << p.log2_wpr) + qq) * p.n + b) * 32 + r];
                     float *dst = p.out + (long)b * p.ldo + (long)srow * 32 + r;
                     v *= osc;
-                    if (p.sk > 1 || (PAIRK && p.sk < 0 && rl == slot_last)) atomicAdd(dst, v);
+                    if (p.sk > 1 || (PAIRK && p.sk < 0 && rl >= wholes)) atomicAdd(dst, v);
                     else if (p.accumulate) *dst += v;  // the residual add of a decoder block: out is the fp32 residual stream
                     else *dst = v;
                 }

@@ -685,15 +685,17 @@ def test_llama70b_row_shard_of_8(qp, oracle, kind, rank):
         _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle)
 
 
-@pytest.mark.parametrize("qstr,m", [("tcomb_6_7_0.5_none_0.9", 8960), ("tcq_6_none_0.9", 8960), ("tcq_5_none_0.9", 5120),
-                                    ("ldlq_1_4_none_1.0", 8960), ("ldlq_2_9_none_1.0", 5120)])
-def test_pair_mode_rows_shared_by_two_workgroups(qp, oracle, qstr, m):
+@pytest.mark.parametrize("qstr,m,k", [("tcomb_6_7_0.5_none_0.9", 8960, 4096), ("tcq_6_none_0.9", 8960, 4096), ("tcq_5_none_0.9", 5120, 4096),
+                                      ("ldlq_1_4_none_1.0", 8960, 4096), ("ldlq_2_9_none_1.0", 5120, 4096),
+                                      ("tcq_6_none_0.9", 28672, 2048), ("tcq_4_none_0.9", 57344, 1024)])
+def test_pair_mode_rows_shared_by_two_workgroups(qp, oracle, qstr, m, k):
     """Pair mode of the GEMV planner (csrc/tc_kernels.h TcParams, qpal_capi.hip plan_launch): two projections of one input whose
     outputs the caller declares zeroed — 2 x 280 rows at 4 rows per workgroup pair up as 7 rows per two workgroups (160 items
-    instead of 140), 2 x 160 rows at 2 rows per workgroup as 3 per two; the shared row's halves meet by atomics.  Against the
-    oracle, against the unpaired launch of the same layers, bit-identical between repeats, and with accumulate."""
+    instead of 140), 2 x 160 rows at 2 rows per workgroup as 3 per two, 2 x 896 rows at 8 per workgroup (Llama-70B's gate | up
+    geometry) as 14 per two with TWO shared rows, 2 x 1792 at 16 as 28 per two with four; the shared rows' halves meet by
+    atomics.  Against the oracle, against the unpaired launch of the same layers, bit-identical between repeats, and with
+    accumulate."""
     import subprocess, textwrap
-    k = 4096
     infos = [qp.mem_op.dummy_linear_info(k, m, qstr, seed=70 + i, codebook_seed=13) for i in range(2)]
     mods = [qp.make_linear_from_info(qstr, info).cuda() for info in infos]
     qp.share_codebooks(mods)
