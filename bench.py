@@ -872,7 +872,7 @@ def whole_model_leg(args):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     model_key, qstr = WORKLOADS[args.workload]
-    argv = ["--model", model_key, "--no-modular", "--tokens", str(max(16, min(args.steps, 64))), "--context", "1024"]
+    argv = ["--model", model_key, "--no-modular", "--tokens", str(max(64, min(args.steps, 256))), "--context", "1024"]
     argv += ["--qdict", qstr[6:]] if qstr.startswith("qdict:") else ["--quantizer", qstr]
     if args.layers:
         argv += ["--layers", str(args.layers)]

@@ -18,7 +18,6 @@ import json
 import math
 import os
 import sys
-import time
 import types
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -163,6 +162,27 @@ def main(argv=None, quiet=False):
             out_tok.copy_(logits.argmax(-1))
         return h
 
+    def _time_tokens(g, feed):
+        """ms-free seconds per token of `args.tokens` replays of the captured step.  The loop that is timed is the loop that is warmed
+        up: with `feed` every token first copies the sampled token in and sets the position (two tiny launches whose FIRST use
+        loads their code objects — ~28 ms that round 3 had inside the timed region: 284 tok/s at 20 tokens against 472 at 64).
+        Timed with events on the replay stream around the whole loop, the host loop runs ahead of the GPU."""
+        def one(i):
+            if feed:                           # the next step consumes the sampled token at the next position
+                tok.copy_(out_tok)
+                pos.fill_(min(args.context - 1, args.start_pos + i))
+            g.replay()
+        for i in range(8):
+            one(i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(args.tokens):
+            one(i)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / args.tokens
+
     def timed(glue):
         s = torch.cuda.Stream(dev)
         with torch.cuda.stream(s):
@@ -171,17 +191,7 @@ def main(argv=None, quiet=False):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s):
                 step(glue)
-            for i in range(4):
-                g.replay()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(args.tokens):
-                if glue:                       # the next step consumes the sampled token at the next position
-                    tok.copy_(out_tok)
-                    pos.fill_(min(args.context - 1, args.start_pos + i))
-                g.replay()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / args.tokens
+            return _time_tokens(g, glue)
 
     # ---- fused glue (MI355X decoder block): the residual stream stays fp32; RMSNorm + sign flip + Hadamard run inside the
     # q|k|v and up|gate launches (x_rms / x_rot on the fp32 stream), o_proj and down_proj ADD into the stream (accumulate),
@@ -324,16 +334,7 @@ def main(argv=None, quiet=False):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s):
                 fused_step()
-            for i in range(4):
-                g.replay()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(args.tokens):
-                tok.copy_(out_tok)
-                pos.fill_(min(args.context - 1, args.start_pos + i))
-                g.replay()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / args.tokens
+            return _time_tokens(g, True)
 
     # the fused step computes what the modular step computes (fp32 residual stream instead of fp16: small differences)
     check = None

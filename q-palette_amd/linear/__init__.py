@@ -215,7 +215,10 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
             # decode-to-HBM + GEMM up to ~2 passes
             # — every pass writes its rows of ONE [n, m] output per layer (no concatenation kernels)
             if any(_codec_key(l)[0] == "single" for l in layers):
-                return [l(x2) for l in layers]
+                # row-split (comb_*) layers and column-split ones with unequal parts have no multi-job form: passes of their
+                # own fused launches (NOT l(x2): the module's forward sends this batch range back here)
+                return [torch.cat([l._gemv(x2[i:i + fused], min(fused, n - i)).float() for i in range(0, n, fused)], dim=0)
+                        for l in layers]
             full = [torch.empty((n, l.out_features), dtype=torch.float32, device=x2.device) for l in layers]
             for i in range(0, n, fused):
                 multi_gemv(layers, x2[i:i + fused], outs=[f[i:i + fused] for f in full])

@@ -610,6 +610,14 @@ def test_comb_layers_with_unequal_parts(qp, oracle, qstr, k, m, part):
         y = layer(x.cuda().float())
         # the column-split form adds two fp32 partial results: one more fp32 rounding than a single kernel
         _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle)
+    # above the fused batch these layers have no multi-job form: passes of their own launches up to max_chunked_batch (this range
+    # used to recurse forever: forward -> multi_gemv -> forward), decode + GEMM beyond
+    for n in (65, 128, 200):
+        x = torch.randn(n, k, generator=gen).half()
+        y = layer(x.cuda())
+        assert y.dtype == torch.float16 and tuple(y.shape) == (n, m)
+        rows = np.array([0, 63, 64, n - 1])
+        _check_gemv(y[rows].float().cpu().numpy(), W, x[rows].numpy(), oracle, fp16_out=True)
 
 
 def test_comb_layer_row_shards(qp, oracle):
