@@ -20,6 +20,7 @@ timed with HIP events on the launch stream; per-launch figures = per-token / 224
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -80,6 +81,8 @@ def parse_args():
                     help="qdict workloads: tensor-core-order vs SIMT packing of the VQ/SQ layers as published (chosen from the "
                          "reference's RTX 4090 latency table) or re-chosen from this GPU's table (perf/latency/)")
     ap.add_argument("--no-kind-breakdown", action="store_true", help="skip the per-launch-kind timing of the default run")
+    ap.add_argument("--no-calibration", action="store_true",
+                    help="skip the calibration block of the roofline (measured stream ceiling, stream token, decode floor)")
     ap.add_argument("--no-swiglu-epilogue", action="store_true",
                     help="--incoherent: up|gate as fp32 outputs and SwiGLU inside the rotation launch (default: interleaved up|gate layer, "
                          "SwiGLU in the GEMV epilogue)")
@@ -422,6 +425,144 @@ def algorithmic_bytes(qp, layers, batch):
     return total
 
 
+_PACKED_NAMES = ("trellis", "trellis1", "trellis2", "qweight")
+
+
+def calibrate(qp, torch, layers, n, device, stream, steps):
+    """Calibration of the roofline block, measured in the SAME run on the SAME box (boxes differ by +-5 %):
+      measured_stream_GBps  one launch of csrc/calib.hip's pure read (16-byte non-temporal loads, 256 x 1024 threads) over 2 GiB
+      stream_token_ms       the token's launch structure with every GEMV launch replaced by that pure read over exactly the packed
+                            buffers the launch decodes (same dependent order, one HIP graph): what the token would take if decode,
+                            staging, reduction and epilogue were free — the boundary, dispatch and first-byte cost of `launches`
+                            dependent launches plus their bytes at the chip's streaming rate
+      decode_floor_ms       the token's wave-steps at the rate the decode + MFMA step of tc_gemv_kernel sustains on register-resident
+                            words (qpal_calib_decode_rate, per TCQ codec of the workload; null when the workload has VQ/SQ layers)."""
+    import ctypes
+
+    lib = qp._native.lib()
+    P, L = ctypes.c_void_p, ctypes.c_long
+    sink = torch.zeros(1024, dtype=torch.int32, device=device)
+    ncu = torch.cuda.get_device_properties(device).multi_processor_count
+
+    def read_launch(tensors):
+        segs = [(t.data_ptr(), t.numel() * t.element_size()) for t in tensors]
+        segs = [(p_, b - b % 16) for p_, b in segs if b >= 16]
+        for i in range(0, len(segs), 16):
+            part = segs[i:i + 16]
+            ptrs = (P * len(part))(*[p_ for p_, _ in part])
+            byts = (L * len(part))(*[b for _, b in part])
+            qp._native.check(lib.qpal_calib_stream_read(ptrs, byts, len(part), sink.data_ptr(), ncu, stream.cuda_stream), "qpal_calib_stream_read")
+
+    def timed(fn, reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    out = {}
+    with torch.cuda.stream(stream):
+        big = torch.empty(2 << 30, dtype=torch.uint8, device=device)
+        read_launch([big])
+        torch.cuda.synchronize()
+        t = min(timed(lambda: read_launch([big]), 3) for _ in range(3))
+        out["measured_stream_GBps"] = big.numel() / t / 1e9
+        out["measured_stream_what"] = "pure read of 2 GiB in one launch (csrc/calib.hip), best of 3 x 3 launches"
+        del big
+        # the stream token: per GEMV launch of the token, a pure read of its packed buffers
+        mixed_kv = n <= 8
+        launches = []
+        for groups in layers:
+            for grp in groups:
+                mods = [m for m, _, _ in grp]
+                for idxs in qp.linear.launch_groups(mods, mixed_kv=mixed_kv):
+                    launches.append([t_ for i in idxs for nm in _PACKED_NAMES if (t_ := getattr(mods[i], nm, None)) is not None])
+
+        def stream_token():
+            for ts in launches:
+                read_launch(ts)
+        stream_token()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            stream_token()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        out["stream_token_ms"] = timed(g.replay, max(5, min(steps, 50))) * 1e3
+        out["stream_token_launches"] = len(launches)
+        # decode floor
+        steps_by_codec, ok = {}, True
+        for groups in layers:
+            for m, k, _ in (u for grp in groups for u in grp):
+                rows = m.out_features // 32
+                if isinstance(m, qp.QTIPLinearTCQ):
+                    key = (m.tlut_bits, m.KV)
+                    steps_by_codec[key] = steps_by_codec.get(key, 0) + rows * -(-k // 128)
+                elif isinstance(m, qp.CombtLinearTCQ):
+                    for kv, kp in zip(m.KV, m.in_part):
+                        key = (m.tlut_bits, kv)
+                        steps_by_codec[key] = steps_by_codec.get(key, 0) + rows * -(-kp // 128)
+                else:
+                    ok = False
+        if ok and steps_by_codec:
+            iters = 400
+            floor, rates = 0.0, {}
+            for (S, kv), wsteps in sorted(steps_by_codec.items()):
+                tl = torch.randn(2 ** S, 2, device=device).half()
+                run = lambda: qp._native.check(lib.qpal_calib_decode_rate(tl.data_ptr(), sink.data_ptr(), iters, S, kv, ncu, stream.cuda_stream),
+                                               "qpal_calib_decode_rate")
+                run()
+                torch.cuda.synchronize()
+                t = min(timed(run, 2) for _ in range(2))
+                rate = ncu * 16 * iters / t  # wave-steps per second, whole chip
+                rates[f"tcq_{S}_{kv}"] = {"wave_steps_per_us_per_cu": rate / ncu / 1e6, "ns_per_wave_step_per_simd_slot": 4e9 * ncu / rate,
+                                         "wave_steps_per_token": wsteps}
+                floor += wsteps / rate
+            out["decode_floor_ms"] = floor * 1e3
+            out["decode_rate"] = rates
+        else:
+            out["decode_floor_ms"] = None
+    return out
+
+
+def usable_cpus():
+    """-> (CPUs visible, CPUs this process can actually use, how that was found).  A GPU box gives a job a SHARE of its host
+    (cgroup CPU quota): 128 visible cores with a quota of 16 run 128 OpenMP threads 8-deep — round 3's "128 cores, 5.7 x one
+    thread" was that.  The baseline uses, and reports, the share."""
+    try:
+        visible = len(os.sched_getaffinity(0))
+    except AttributeError:
+        visible = os.cpu_count() or 1
+    quota, why = None, "affinity mask"
+    for path in ("/sys/fs/cgroup/cpu.max", ):
+        try:
+            with open(path) as f:
+                q, per = f.read().split()[:2]
+            if q != "max":
+                quota = max(1, int(math.ceil(int(q) / int(per))))
+                why = f"cgroup v2 cpu.max = {q} {per}"
+        except (OSError, ValueError):
+            pass
+    if quota is None:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                quota = max(1, int(math.ceil(q / per)))
+                why = f"cgroup v1 cfs quota {q} / {per}"
+        except (OSError, ValueError):
+            pass
+    env = os.environ.get("QPAL_CPU_THREADS")
+    if env:
+        return visible, int(env), "QPAL_CPU_THREADS"
+    return visible, (min(visible, quota) if quota else visible), why
+
+
 def cpu_baseline(qp, layers, batch, seconds, nl=None):
     """CPU baseline (kind "port": the oracle's restatement of what the reference does without a GPU — fake-dequant to fp16 W,
     then fp32-accumulate x @ W.T; lib/quantizer/quant_op.py:185-201, lib/utils/kernel_decompress.py:64-88) on ONE layer's
@@ -459,7 +600,9 @@ def cpu_baseline(qp, layers, batch, seconds, nl=None):
         return float(np.median(ts)), len(ts)
 
     nl = nl or len(layers)
-    ncores = oracle.num_threads()
+    visible, ncores, why = usable_cpus()
+    ncores = max(1, min(ncores, oracle.num_threads()))
+    oracle.set_num_threads(ncores)  # threads actually used = the CPUs this process may really run on (cgroup quota), not nproc
     variants = {}
     run_one(host[0], False)  # warm-up: page faults, table init
     budget = max(2.0, seconds) / 3.0
@@ -484,7 +627,14 @@ def cpu_baseline(qp, layers, batch, seconds, nl=None):
     finally:
         oracle.set_num_threads(ncores)
     best = variants["materialise_all_cores"]
+    one = variants["materialise_1_thread"]["value"]
+    speedup = best["value"] / one if one > 0 else None
     return {"value": best["value"], "unit": "tokens/s", "cores": ncores, "kind": "port",
+            "host_cpus_visible": visible, "cores_source": why,
+            # how well the all-core figure scales: the decode is table-driven scalar code, the GEMV a stream over W — beyond the
+            # host's memory channels more threads buy little (round 3: 5.7x on 128 threads).  The one-thread figure is beside it.
+            "one_thread_value": one, "speedup_over_one_thread": speedup,
+            "parallel_efficiency": (speedup / ncores) if speedup else None,
             "sample": f"1 of {nl} layers ({len(host)} linears, batch {batch}), median of {best['layer_runs']} full-layer runs; "
                       f"per-token time = {nl} x per-layer time",
             "variants": variants}
@@ -711,6 +861,13 @@ def main():
         except Exception as exc:  # the headline line must not depend on this leg
             by_kind = {"error": repr(exc)}
 
+    calib = None
+    if world == 1 and not args.incoherent and not args.no_calibration and graph is not None:
+        try:
+            calib = calibrate(qp, torch, layers, n, device, main_stream, args.steps)
+        except Exception as exc:  # the headline line must not depend on this leg
+            calib = {"error": repr(exc)}
+
     # Second figure (N = 1 only, after the timed region of the headline): the same token with every projection group
     # inside the reference's incoherence wrapper (rotation + scales), i.e. what an IncoherentMLP / attention forward costs.
     extra = None
@@ -789,6 +946,12 @@ def main():
     }
     if by_kind is not None:
         out["roofline"]["by_launch_kind"] = by_kind
+    if calib is not None:
+        out["roofline"].update(calib)
+        if calib.get("measured_stream_GBps"):
+            out["roofline"]["frac_of_measured"] = achieved / calib["measured_stream_GBps"]
+        if calib.get("stream_token_ms"):
+            out["roofline"]["frac_of_stream_token"] = calib["stream_token_ms"] / (t_token * 1e3)
     if n > 8:  # skinny GEMM / decode + fp16 GEMM: a dense contraction, priced against the matrix pipe as well
         flops = 2.0 * n * sum(m.out_features * k for groups in layers for grp in groups for m, k, _ in grp)
         out["roofline_mfma"] = {"bound": "mfma", "achieved": flops / t_token / 1e12, "peak": 2500.0, "unit": "TFLOP/s",

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define QPAL_VERSION 220
+#define QPAL_VERSION 230
 
 #define QPAL_OK 0
 #define QPAL_E_SHAPE (-1)   /* m, k, n outside the supported set (m%32, k%32, 1<=n<=64 ...) */
@@ -322,6 +322,18 @@ int qpal_attn_rope_decode(const float *q, const float *k, const float *v, void *
 int qpal_can_fuse_rotation(int n, int k);
 /* the same for x_K > 1 (K = 28, k = 14336, batch 1; codecs whose codebook image is >= 40 KiB: every TCQ codec) */
 int qpal_can_fuse_rotation_k(int n, int k, int K);
+
+/* Calibration of the measurement contract (bench.py `roofline` block; SURVEY.md §8d: "report a measured stream-read ceiling").
+ * NOT on the data path — no module calls them; csrc/calib.hip.
+ *   qpal_calib_stream_read  one launch (`grid` workgroups of 1024 threads) that does nothing but read srcs[i] (bytes[i] bytes each,
+ *                           16-byte aligned, bytes % 16 == 0, nseg <= 16) with 16-byte non-temporal loads; sink: >= 4 KiB of
+ *                           device memory (never written in practice).  Over > 1 GB: the stream ceiling; over the packed buffers
+ *                           of one GEMV launch: what that launch would take if the decode were free.
+ *   qpal_calib_decode_rate  `grid` workgroups of 16 waves run `iters` decode + MFMA steps of the TCQ codec (S, KV) — the step
+ *                           function of the fused GEMV kernel itself — on register-resident packed words: no HBM traffic.
+ *                           wave-steps executed = grid * 16 * iters (one step = 32 rows x 128 columns of W).            */
+int qpal_calib_stream_read(const void *const *srcs, const long *bytes, int nseg, void *sink, int grid, void *stream);
+int qpal_calib_decode_rate(const void *tlut, void *sink, int iters, int S, int KV, int grid, void *stream);
 
 const char *qpal_error_string(int code);
 int qpal_version(void);

@@ -56,6 +56,14 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
         const char *nm[8] = {"", "issue-w", "x+lut", "barrier", "steps", "xor-red", "barrier2", "final"};
         for (int i = 1; i < 8; i++) printf(" %s %.2f/%.2f", nm[i], ph[i] / (nw ? nw : 1) / 100.0, phmax[i] / 100.0);
         printf("\n");
+        if (const char *dump = getenv("QPAL_STAMPS_DUMP")) {  // raw stamps for offline analysis: one binary file per stamped launch
+            char path[512];
+            snprintf(path, sizeof path, "%s_%s_grid%d_m%d_k%d.bin", dump, ROT == 3 ? "pair" : ROT ? "rot" : "plain", grid, p.nrows * 32, p.k);
+            if (FILE *f = fopen(path, "wb")) {
+                fwrite(h, 1, nb, f);
+                fclose(f);
+            }
+        }
         free(h);
         hipFree(d);
     }
