@@ -1,0 +1,122 @@
+// How long after a wave's first instruction does its first memory access land, inside a chain of dependent launches?
+// Round 4: the steady-state stamps of the GEMV kernels (perf/stamps_replay.py) show loads issued at instruction 0 landing ~2.5 us
+// later and the kernel-argument block ~1.1 us later — most of a short launch.  Is that the price of ANY first access after a kernel
+// boundary, or of what the previous kernel leaves behind (dirty lines, atomics, streamed weights)?
+//   hipcc --offload-arch=gfx950 -O3 perf/first_touch.hip -o perf/first_touch.bin
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <algorithm>
+#include <vector>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct Big { int v[320]; };
+
+// what the probe does at entry, by bits of `mode`:
+//   1: vector load of a small SHARED buffer (16 B per thread of the first 512 threads: an activation vector)
+//   2: scalar load from the kernel-argument block (behind 1.25 KB of arguments)
+//   4: vector load of this wave's own 1.75 KB of a big buffer (a first weight step), cold
+//   8: 4-byte gathers from a 2 KB table (4 per thread: the codebook-image entries)
+// tail, by bits of `tail`: 1: every workgroup stores 448 B of zeros (a prezero share); 2: 32 float atomics per wave into `out`
+template <int MODE>
+__global__ __launch_bounds__(1024) void probe(const u32x4 *x, const uint32_t *tab, const u32x4 *w, float *out, u32x4 *zero, int tail,
+                                              unsigned long long *st, long wstride, const Big b) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const int tid = threadIdx.x, wave = tid >> 6;
+    u32x4 vx{0, 0, 0, 0}, vw{0, 0, 0, 0};
+    uint32_t vt[4] = {0, 0, 0, 0};
+    int k = 0;
+    if (MODE & 1) { if (tid < 512) vx = x[tid]; }
+    if (MODE & 8) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) vt[r] = tab[((tid + r * 1024) >> 2) & 511];
+    }
+    if (MODE & 2) k = b.v[300];
+    if (MODE & 4) vw = __builtin_nontemporal_load(w + (long)blockIdx.x * wstride + tid * 2);
+    unsigned long long tk = 0, tx = 0, tw = 0;
+    if (MODE & 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(k) : "memory"); tk = __builtin_amdgcn_s_memrealtime(); }
+    if (MODE & (1 | 8)) {
+        if (MODE & 4) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tx = __builtin_amdgcn_s_memrealtime();
+    }
+    if (MODE & 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tw = __builtin_amdgcn_s_memrealtime(); }
+    const uint32_t f = vx.x ^ vx.w ^ vw.x ^ vw.z ^ vt[0] ^ vt[1] ^ vt[2] ^ vt[3] ^ (uint32_t)k;
+    if ((tid & 63) == 0) {
+        unsigned long long *d = st + ((long)blockIdx.x * 16 + wave) * 4;
+        d[0] = t0; d[1] = tk; d[2] = tx; d[3] = tw;
+    }
+    if (f == 0x12345679u) st[0] = 1;
+    if (tail & 1) { if (tid < 28) zero[blockIdx.x * 28 + tid] = u32x4{0, 0, 0, 0}; }
+    if (tail & 2) { if ((tid & 63) < 32) atomicAdd(out + ((blockIdx.x >> 1) * 32 + (tid & 31)), 1.0f); }
+}
+
+// a 16-byte-per-thread stream over `bytes` (what a GEMV launch leaves in the caches)
+__global__ __launch_bounds__(1024) void stream(const u32x4 *w, long n, uint32_t *sink) {
+    u32x4 acc{0, 0, 0, 0};
+    for (long i = blockIdx.x * 1024L + threadIdx.x; i < n; i += gridDim.x * 1024L) acc ^= __builtin_nontemporal_load(w + i);
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[0] = 1;
+}
+
+template <int MODE>
+void run(const char *what, int tail, int stream_mb, u32x4 *x, uint32_t *tab, u32x4 *w, float *out, u32x4 *zero, unsigned long long *st) {
+    Big b{};
+    hipStream_t s; (void)hipStreamCreate(&s);
+    hipGraph_t g; hipGraphExec_t ge;
+    const int N = 40;
+    const long wstride = 112;  // 1.75 KB per wave-step x 16 waves = 28 KB per workgroup = 1792 u32x4
+    (void)hipStreamBeginCapture(s, hipStreamCaptureModeGlobal);
+    for (int i = 0; i < N; i++) {
+        if (stream_mb) hipLaunchKernelGGL(stream, dim3(256), dim3(1024), 0, s, w + (long)(i % 16) * (64 << 16), (long)stream_mb << 16, (uint32_t *)st);
+        hipLaunchKernelGGL((probe<MODE>), dim3(256), dim3(1024), 0, s, x, tab + (i % 4) * 512, w + (long)(i % 16) * (64 << 16) + (48 << 16), out, zero, tail, st,
+                           wstride * 16, b);
+    }
+    (void)hipStreamEndCapture(s, &g);
+    (void)hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    std::vector<unsigned long long> h(256 * 16 * 4);
+    double sum[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0}, spread = 0;
+    const int reps = 10;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float ms = 0;
+    for (int r = 0; r < reps + 2; r++) {
+        (void)hipEventRecord(e0, s);
+        (void)hipGraphLaunch(ge, s);
+        (void)hipEventRecord(e1, s);
+        (void)hipStreamSynchronize(s);
+        if (r < 2) continue;
+        float m; (void)hipEventElapsedTime(&m, e0, e1); ms += m;
+        (void)hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long lo = ~0ull, hi = 0;
+        for (int wv = 0; wv < 256 * 16; wv++) {
+            const unsigned long long t0 = h[wv * 4];
+            lo = std::min(lo, t0); hi = std::max(hi, t0);
+            for (int j = 1; j < 4; j++) if (h[wv * 4 + j]) { const double d = (double)(h[wv * 4 + j] - t0) / 100.0; sum[j] += d; mx[j] = std::max(mx[j], d); }
+        }
+        spread += (double)(hi - lo) / 100.0;
+    }
+    const double n = (double)reps * 256 * 16;
+    printf("%-58s tail %d, %2d MB streamed before: kernarg %.2f (max %.2f)  shared/table loads %.2f (max %.2f)  own cold 1.75 KB %.2f (max %.2f) us after entry; "
+           "entries spread %.2f; %.2f us per probe launch%s\n", what, tail, stream_mb, sum[1] / n, mx[1], sum[2] / n, mx[2], sum[3] / n, mx[3], spread / reps,
+           ms / reps * 1e3 / N, stream_mb ? " (+ stream launch)" : "");
+    (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g); (void)hipStreamDestroy(s);
+}
+
+int main() {
+    u32x4 *x, *w, *zero; uint32_t *tab; float *out; unsigned long long *st;
+    (void)hipMalloc(&x, 8192); (void)hipMalloc(&tab, 8192); (void)hipMalloc(&w, 1L << 30); (void)hipMalloc(&out, 1 << 16);
+    (void)hipMalloc(&zero, 1 << 18); (void)hipMalloc(&st, 256 * 16 * 4 * 8);
+    (void)hipMemset(x, 1, 8192); (void)hipMemset(tab, 1, 8192); (void)hipMemset(w, 1, 1L << 30); (void)hipMemset(out, 0, 1 << 16); (void)hipMemset(st, 0, 256 * 16 * 32);
+    for (int tail : {0, 1, 2, 3}) {
+        run<1>("shared 8 KB vector only", tail, 0, x, tab, w, out, zero, st);
+        run<2>("kernel-argument scalar load only", tail, 0, x, tab, w, out, zero, st);
+        run<4>("own cold 1.75 KB only", tail, 0, x, tab, w, out, zero, st);
+        run<8>("table gathers only", tail, 0, x, tab, w, out, zero, st);
+        run<15>("all four (a GEMV prologue)", tail, 0, x, tab, w, out, zero, st);
+    }
+    for (int mb : {8, 48}) {
+        run<1>("shared 8 KB vector only", 0, mb, x, tab, w, out, zero, st);
+        run<15>("all four (a GEMV prologue)", 0, mb, x, tab, w, out, zero, st);
+        run<15>("all four (a GEMV prologue)", 3, mb, x, tab, w, out, zero, st);
+    }
+    return 0;
+}

@@ -20,6 +20,13 @@ for path in sys.argv[1:]:
         sl = slice(lo, hi)
         print(f"  blocks {lo:3d}-{hi - 1:3d}: start {np.nanmean(start[sl]) - t0:5.2f}  first-weights {np.nanmean(first_w[sl]) - t0:5.2f}  "
               f"steps-end {np.nanmean(steps_end[sl]) - t0:5.2f} (max {np.nanmax(steps_end[sl]) - t0:5.2f})  end {np.nanmax(end[sl]) - t0:5.2f}")
+    if (a[:, :, 2][live] > 0).all():  # early-staging launches of a round-4 STAMPS build: slot 2 = wave entry, slot 3 = early loads landed
+        entry, landed = np.where(live, a[:, :, 2], np.nan), np.where(live, a[:, :, 3], np.nan)
+        e0 = np.nanmin(entry)
+        print(f"  per wave, us: entry -> kernel arguments in hand (stamp 0) {np.nanmean(start - entry):.2f} (max {np.nanmax(start - entry):.2f}); entry -> early x / table "
+              f"loads landed {np.nanmean(landed - entry):.2f} (max {np.nanmax(landed - entry):.2f}); landed -> staged + barrier (stamp 1) {np.nanmean(first_w - landed):.2f}; "
+              f"wave entries spread over {np.nanmax(entry) - e0:.2f} (inside a workgroup {np.nanmean(np.nanmax(entry, axis=1) - np.nanmin(entry, axis=1)):.2f}); "
+              f"first entry -> last end {np.nanmax(end) - e0:.2f}")
     per_block_start = np.nanmin(start, axis=1) - t0
     order = np.argsort(per_block_start)
     r = np.corrcoef(np.arange(nb), per_block_start)[0, 1]

@@ -181,6 +181,19 @@ struct TcqCodec {
     static __device__ __forceinline__ void build(uint32_t *lds, const void *tab, int tid, int nthreads) {
         build_image<CHUNKS, LOG2C, U>(lds, tid, nthreads, [&](int e) { return entry(tab, e); });
     }
+    // Early staging (tc_gemv_kernel): entry(tab, e) == fix(raw(tab, e), e), split so that the loads can be requested at the wave's
+    // first instruction with NO arithmetic hanging on them — round 4 found `s_waitcnt vmcnt(0)` + the sign xor right behind the
+    // table loads, in front of the kernel-argument loads and the first weight loads: three memory round trips in a row where one
+    // was meant (perf/stamps_replay.py: kernel arguments in hand 1.1 us after the wave's entry, first weights requested after that).
+    // The loads are issued from inline asm, i.e. OUTSIDE the compiler's wait-count bookkeeping: with loads it knows about it put
+    // conservative waits (vmcnt(0) at control-flow joins, register copies at a loop header) in front of the first weight loads
+    // whatever the source looked like.  tc_gemv_kernel waits for them by hand (early_landed) where it consumes them.
+    static constexpr int RAWN = 1;
+    static __device__ __forceinline__ void raw_issue(const void *tab, int e, uint32_t (&r)[RAWN]) {
+        const uint32_t off = (uint32_t)(e & ((1 << S) - 1)) * 4u;
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(r[0]) : "v"(off), "s"(tab));
+    }
+    static __device__ __forceinline__ uint32_t fix(const uint32_t (&r)[RAWN], int e) { return r[0] ^ (((uint32_t)e >> S) << 15); }
 
     // (A << L4) | B in the low 2*L4 bits (KV <= 4 only: 2*L4 <= 32)
     template <int G>
@@ -288,6 +301,22 @@ struct LutCodec {
     template <int U = kBuildInFlight>  // table reads in flight per thread
     static __device__ __forceinline__ void build(uint32_t *lds, const void *tab, int tid, int nthreads) {
         build_image<CHUNKS, LOG2C, U>(lds, tid, nthreads, [&](int e) { return entry(tab, e); });
+    }
+    // early staging: loads and the arithmetic on them apart (see TcqCodec::raw)
+    static constexpr int RAWN = PAIR ? 2 : 1;
+    static __device__ __forceinline__ void raw_issue(const void *tab, int e, uint32_t (&r)[RAWN]) {
+        if constexpr (VEC == 2) {
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(r[0]) : "v"((uint32_t)e * 4u), "s"(tab));
+        } else if constexpr (PAIR) {
+            asm volatile("global_load_ushort %0, %1, %2" : "=v"(r[0]) : "v"((uint32_t)(e & ((1 << BITS) - 1)) * 2u), "s"(tab));
+            asm volatile("global_load_ushort %0, %1, %2" : "=v"(r[1]) : "v"((uint32_t)(e >> BITS) * 2u), "s"(tab));
+        } else {
+            asm volatile("global_load_ushort %0, %1, %2" : "=v"(r[0]) : "v"((uint32_t)e * 2u), "s"(tab));
+        }
+    }
+    static __device__ __forceinline__ uint32_t fix(const uint32_t (&r)[RAWN], int) {
+        if constexpr (PAIR) return r[0] | (r[1] << 16);
+        else return r[0];
     }
 
     template <int G>
@@ -603,11 +632,10 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t laneoff = (uint32_t)(lane & (C1::C - 1)) << 2;
+#ifdef QPAL_STAMPS
+    const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();  // the wave's first instruction (slot 2 of an early-staging launch)
+#endif
 
-    union {
-        uint32_t a[C1::NW];
-        uint32_t b[CB::NW];
-    } w;
     const void *cur_tab = nullptr;      // codebook whose image is in LDS
     const uint16_t *cur_x = nullptr;    // activations staged in LDS
     int cur_j = 0;
@@ -624,21 +652,25 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     constexpr int EV = NV < 4 ? NV : 4;  // image entries a thread holds across the argument fetch; the rest are built after it
     constexpr int XR = kEarlyXChunks;    // 16-byte chunks of x a thread holds likewise
     [[maybe_unused]] u32x4 exr[XR];
-    [[maybe_unused]] uint32_t etv[EV];
+    [[maybe_unused]] uint32_t etv[EV][C1::RAWN];
     const bool early = kEarly && eon != 0;
     if constexpr (kEarly) {
+        // Nothing in this block may USE what it loads (round 4): a use makes the compiler wait for the loads right here, in front of
+        // the kernel-argument fetch below and of the first weight loads behind that — the round trips this block exists to overlap.
         if (early) {
             const int total = en * ek;
 #pragma unroll
             for (int r = 0; r < XR; r++) {
                 const int i = tid * 8 + r * (NT * 8);
-                exr[r] = u32x4{0u, 0u, 0u, 0u};
-                if (i < total) exr[r] = *reinterpret_cast<const u32x4 *>(ex + i);
+                // (clamped instead of predicated: no zero-fill to merge with the load; part 2 stores only i < total + 32 and
+                // overwrites the pad chunk with zeros)
+                const uint32_t off = (uint32_t)(i < total ? i : 0) * 2u;
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(exr[r]) : "v"(off), "s"(ex));
             }
 #pragma unroll
             for (int r = 0; r < EV; r++) {
                 const int c = tid + r * NT;
-                etv[r] = C1::entry(etab, ((c < C1::CHUNKS ? c : 0) * 4) >> C1::LOG2C);
+                C1::raw_issue(etab, ((c < C1::CHUNKS ? c : 0) * 4) >> C1::LOG2C, etv[r]);
             }
         }
     }
@@ -652,7 +684,19 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     // it has waited for the item table — two kernel-argument round trips on the critical path instead of one.
     asm volatile("" ::"s"(p.c1), "s"(p.c2), "s"(p.x), "s"(p.tab), "s"(p.nrows), "s"(p.nsc1), "s"(p.log2_wpr), "s"(p.sk),
                  "s"(p.out), "s"(ie[0]), "s"(p.wscale), "s"(p.base2));
-    for (int gitem = blockIdx.x; gitem < total_items; gitem += gridDim.x) {
+    // One work item.  FIRST (this workgroup's first item, compile-time): the only one that consumes the early-staged registers —
+    // a body of its own, so that those registers are plain straight-line values: as values carried into a loop they were copied
+    // at the loop header, and the copy waits for the loads (round 4, see TcqCodec::raw).
+    auto run_item = [&](const int gitem, auto first_c) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        // (declared per item: as a capture of this lambda it ended up in scratch memory.  Two arrays, not a union: `on2` is
+        // wave-uniform but the compiler lays the two typed loads out as branches that may BOTH run, and with shared registers
+        // the second branch waited — vmcnt(0) — for the first one's loads, i.e. for the early x / table loads, before it issued
+        // its own: the weights of half of the waves were requested a memory round trip late)
+        struct {
+            uint32_t a[C1::NW];
+            uint32_t b[TWO ? CB::NW : 1];
+        } w;
         int j = 0, item_begin = 0;
 #pragma unroll
         for (int i = 0; i < kMaxJobs - 1; i++) {
@@ -740,6 +784,25 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
             });
         });
 
+        // Early staging, part 2a: the early loads were issued from inline asm, i.e. outside the compiler's wait-count bookkeeping —
+        // wait for them by hand, HERE: ~0.2-0.3 us after the wave's entry they and the kernel arguments have arrived together
+        // (perf/first_touch.hip), and from here on every load in flight is one the compiler knows about.  (Requesting the weights
+        // before this wait — they need nothing but the kernel arguments — was tried first: the hardware counter cannot tell the
+        // hidden loads from the compiler's own, and the hazard waits the compiler puts between the two typed weight-load branches
+        // then wait for the early loads anyway, at points no source change moved.)  Every early value then passes through an
+        // (empty) volatile asm, which orders its uses behind the wait.
+        if constexpr (kEarly) {
+            if (FIRST && early) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < XR; r++) asm volatile("" : "+v"(exr[r]));
+#pragma unroll
+                for (int r = 0; r < EV; r++) {
+#pragma unroll
+                    for (int q = 0; q < C1::RAWN; q++) asm volatile("" : "+v"(etv[r][q]));
+                }
+            }
+        }
         // first step's weights are in flight while x and the codebook image are (re)staged
         bool lut_job = false;  // workgroup-uniform
         if constexpr (is_mix_v<C1>) lut_job = p.lut_bits != 0;
@@ -757,21 +820,35 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                     load_step_w<KVr>(on2 ? sv2 : sv1, s0, lane, reinterpret_cast<uint32_t(&)[KVr]>(w.a));
                 });
         } else {
-            if (on2) load_step_w<CB::NW>(sv2, s0, lane, w.b);
-            else load_step_w<C1::NW>(sv1, s0, lane, w.a);
+            if constexpr (TWO) {
+                if (on2) load_step_w<CB::NW>(sv2, s0, lane, w.b);
+                else load_step_w<C1::NW>(sv1, s0, lane, w.a);
+            } else {
+                load_step_w<C1::NW>(sv1, s0, lane, w.a);
+            }
         }
         if constexpr (kEarly) {
-            if (early && gitem == (int)blockIdx.x) {  // early staging, part 2: registers -> LDS
+            if (FIRST && early) {  // early staging, part 2b: registers -> LDS
                 const int total = en * ek;
+#ifdef QPAL_STAMPS
+                if (p.dbg) {  // slot 2: the wave's first instruction; slot 3: the early x / table loads (older than the first weight loads) have landed
+                    const unsigned long long t_landed = __builtin_amdgcn_s_memrealtime();
+                    if (lane == 0) {
+                        p.dbg[((long)blockIdx.x * 16 + wave) * 8 + 2] = t_entry;
+                        p.dbg[((long)blockIdx.x * 16 + wave) * 8 + 3] = t_landed;
+                    }
+                }
+#endif
 #pragma unroll
                 for (int r = 0; r < XR; r++) {
                     const int i = tid * 8 + r * (NT * 8);
-                    if (i < total + 32) xs_put(xs, i, exr[r]);
+                    if (i < total + 32) xs_put(xs, i, i < total ? exr[r] : u32x4{0u, 0u, 0u, 0u});
                 }
 #pragma unroll
                 for (int r = 0; r < EV; r++) {
                     const int c = tid + r * NT;
-                    if (c < C1::CHUNKS) reinterpret_cast<u32x4 *>(lut)[c] = u32x4{etv[r], etv[r], etv[r], etv[r]};
+                    const uint32_t v = C1::fix(etv[r], ((c < C1::CHUNKS ? c : 0) * 4) >> C1::LOG2C);
+                    if (c < C1::CHUNKS) reinterpret_cast<u32x4 *>(lut)[c] = u32x4{v, v, v, v};
                 }
                 if constexpr (EV < NV) {  // (8-wave experiment build only)
                     for (int c = tid + EV * NT; c < C1::CHUNKS; c += NT) {
@@ -784,7 +861,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                 __syncthreads();
             }
         }
-        if (gitem == (int)blockIdx.x && mp.zero_chunks > 0) {  // pre-zero a buffer for a later split-K launch on this stream
+        if (FIRST && mp.zero_chunks > 0) {  // pre-zero a buffer for a later split-K launch on this stream
             for (int i = blockIdx.x * NT + tid; i < mp.zero_chunks; i += gridDim.x * NT) mp.zero[i] = u32x4{0u, 0u, 0u, 0u};
         }
         QPAL_STAMP(1);
@@ -934,14 +1011,17 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         } else
         if constexpr (NBG == 1) {
             if (x_lds) {
-                if (on2) gemv_run<CB, true, 1>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                if constexpr (!TWO) gemv_run<C1, true, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else if (on2) gemv_run<CB, true, 1>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
                 else gemv_run<C1, true, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
             } else {
-                if (on2) gemv_run<CB, false, 1>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                if constexpr (!TWO) gemv_run<C1, false, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else if (on2) gemv_run<CB, false, 1>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
                 else gemv_run<C1, false, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
             }
         } else {
-            if (on2) gemv_run<CB, false, NBG>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+            if constexpr (!TWO) gemv_run<C1, false, NBG>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else if (on2) gemv_run<CB, false, NBG>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
             else gemv_run<C1, false, NBG>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
         }
         QPAL_STAMP(4);
@@ -1007,6 +1087,11 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         }
         QPAL_STAMP(7);
         __syncthreads();
+    };
+    int gitem = blockIdx.x;
+    if (gitem < total_items) {
+        run_item(gitem, std::true_type{});
+        for (gitem += gridDim.x; gitem < total_items; gitem += gridDim.x) run_item(gitem, std::false_type{});
     }
 }
 

@@ -14,6 +14,28 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
     using C1 = TcqCodec<S, KV1>;
     using C2 = std::conditional_t<KV2 == 0, void, TcqCodec<S, KV2 == 0 ? KV1 : KV2>>;
 #ifdef QPAL_STAMPS
+    // QPAL_STAMPS_BUF=<device address>: EVERY launch stamps into a caller-owned buffer (slot per launch shape: 8 slots of
+    // 256 x 16 x 8 u64), also inside a captured graph — the steady-state timeline of a replayed token (perf/stamps_replay.py)
+    if (const char *sb = getenv("QPAL_STAMPS_BUF")) {
+        static int keys[8] = {0};
+        static int nkeys = 0;
+        const int key = grid * 131 + p.k + ROT * 7 + 1;
+        int slot = -1;
+        for (int i = 0; i < nkeys; i++)
+            if (keys[i] == key) slot = i;
+        if (slot < 0 && nkeys < 8) {
+            slot = nkeys;
+            keys[nkeys++] = key;
+            fprintf(stderr, "[stamps-slot] %d %s grid %d m %d k %d wpr %d sk %d\n", slot, ROT == 3 ? "pair" : ROT ? "rot" : "plain", grid, p.nrows * 32, p.k,
+                    1 << p.log2_wpr, p.sk);
+        }
+        if (slot >= 0 && grid <= 256) {
+            TcMultiParams mq = mp;
+            mq.job[0].dbg = reinterpret_cast<unsigned long long *>(strtoull(sb, nullptr, 0)) + (size_t)slot * 256 * 16 * 8;
+            hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(64 * gemv_waves<NBG>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, mq);
+            return (int)hipGetLastError();
+        }
+    }
     // diagnostic build: stamp the first launch of every grid size and print the per-phase shares
     static int seen[8] = {0};
     static int nseen = 0;
