@@ -20,10 +20,19 @@ def main():
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--workload", default="llama3.1-8b_tcomb_6_7")
     ap.add_argument("--replays", type=int, default=20)
+    ap.add_argument("--decode", action="store_true", help="the whole-model fused decode step of perf/decode_llama.py (rotating kernels) instead of the plain token")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     buf = torch.zeros(8 * 256 * 16 * 8, dtype=torch.int64, device=dev)
     os.environ["QPAL_STAMPS_BUF"] = hex(buf.data_ptr())
+    if args.decode:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_dl", os.path.join(ROOT, "perf", "decode_llama.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.main(["--no-modular", "--tokens", "16", "--layers", str(args.layers), "--context", "1024"], quiet=True)
+        torch.cuda.synchronize()
+        return report(buf)
     import bench
     import qpalette_amd as qp
 
@@ -45,25 +54,32 @@ def main():
         for _ in range(args.replays):
             g.replay()
         torch.cuda.synchronize()
-    a = buf.cpu().numpy().astype(np.float64).reshape(8, 256, 16, 8) / 100.0
-    names = ["kernarg in hand (0)", "staged+barrier (1)", "entry (2)", "early loads landed (3)", "steps done (4)", "partials in LDS (5)", "barrier2 (6)", "stored (7)"]
+    report(buf)
+
+
+def report(buf):
+    raw = buf.cpu().numpy().astype(np.uint64).reshape(8, 256, 16, 8)
+    since_entry = (raw[:, :, :, 0] >> np.uint64(52)).astype(np.float64) / 100.0  # stamp 0 - wave entry, us
+    raw[:, :, :, 0] &= np.uint64((1 << 52) - 1)
+    a = raw.astype(np.float64) / 100.0
+    names = ["kernel arguments in hand", "x + image staged (barrier)", "(2)", "(3)", "steps done", "partials in LDS", "barrier 2", "stored"]
     for slot in range(8):
         t = a[slot]
         live = (t[:, :, 0] > 0) & (t[:, :, 7] > 0)
         if not live.any():
             continue
         nb = int(live.any(axis=1).sum())
-        has_entry = bool((t[:, :, 2][live] > 0).all())
-        e = np.where(live, t[:, :, 2] if has_entry else t[:, :, 0], np.nan)
+        e = np.where(live, t[:, :, 0] - since_entry[slot], np.nan)  # wave entry
         e0 = np.nanmin(e)
-        def rel(i):
-            return np.where(live, t[:, :, i], np.nan) - e
-        line = f"slot {slot}: {nb} workgroups stamped; first entry -> last stored {np.nanmax(np.where(live, t[:, :, 7], np.nan)) - e0:.2f} us; entries spread {np.nanmax(e) - e0:.2f}"
-        order = [0, 3, 1, 4, 5, 6, 7] if has_entry else [1, 4, 5, 6, 7]
-        for i in order:
-            r = rel(i)
+        line = (f"slot {slot}: {nb} workgroups stamped; first wave entry -> last stored {np.nanmax(np.where(live, t[:, :, 7], np.nan)) - e0:.2f} us; "
+                f"entries spread over {np.nanmax(e) - e0:.2f}")
+        for i in (0, 2, 3, 1, 4, 5, 6, 7):
+            col = np.where(live & (t[:, :, i] > 0), t[:, :, i], np.nan)
+            if np.isnan(col).all():
+                continue
+            r = col - e
             line += f" | {names[i]} {np.nanmean(r):.2f}/{np.nanmax(r):.2f}"
-        print(line + "   (us after the wave's entry, mean/max over waves)")
+        print(line + "   (us after the wave's own entry, mean/max over waves)")
 
 
 if __name__ == "__main__":

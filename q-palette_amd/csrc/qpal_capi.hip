@@ -189,7 +189,7 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves 
             const int min_steps = ((out_zeroed && out_zeroed[j]) || p.accumulate) ? 2 : 6;
             while (sk * 2 <= want && per_wave / (sk * 2) * 2 >= min_steps) sk *= 2;
         }
-        if (force_sk > 0) sk = force_sk;
+        if (force_sk > 0 && (force_sk & (force_sk - 1)) == 0) sk = force_sk;  // (the kernel splits items by shift and mask)
         set_chunks(p, log2_wpr, sk, waves);
     }
     // Pair mode (TcParams::pair): 4 or 2 rows per workgroup, nothing split, every output zeroed (or accumulated onto) and the

@@ -487,15 +487,67 @@ __device__ __forceinline__ void gemv_step(const uint32_t *lut, uint32_t laneoff,
     });
 }
 
+// Weights of step `step` when it exists (step < s1); otherwise every lane reads the stream's first 16 + bytes — a prefetch slot that
+// costs an instruction and a wait-count slot but no bandwidth.  Always issued: a load under a branch makes the compiler's wait
+// counts conservative (it must assume the shorter queue), which silently turns a two-deep prefetch into a one-deep one.
+template <int NW>
+__device__ __forceinline__ void load_step_w_or_dummy(const StreamView &sv, int step, int s1, int lane, uint32_t (&w)[NW]) {
+    int sc = step * 4 + (lane >> 4);
+    sc = sc < sv.nsc ? sc : sv.nsc - 1;
+    const uint32_t off = (uint32_t)sc * (16u * NW) + (uint32_t)(lane & 15) * NW;
+    load_words_nt<NW>(sv.base + (step < s1 ? off : 0u), w);
+}
+
 // steps [s0, s1) of one stream; `w` already holds step s0 (loaded before the codebook image was built).
-// Two register sets ping-pong (loop unrolled by 2) so the one-step-ahead prefetch costs no copies.
-// (Round 3, measured: deeper prefetch — two or three steps in flight, whole rounds of 3 / 4 steps without a branch so that the
-// compiler's vmcnt bookkeeping stays exact — is 10-19 % SLOWER on every launch kind: profiles/r03_ab_ring.txt, DESIGN.md §4.9.
-// The steps phase is bound by the LDS gathers and the VALU together, not by load latency.)
+// QPAL_PREFETCH_DEPTH == 1 (rounds 1-3): two register sets ping-pong (loop unrolled by 2), one step ahead.
+// QPAL_PREFETCH_DEPTH == 2 (round 4): three register sets, TWO steps ahead.  Why: the in-kernel stamps of round 4 have a wave's
+// step at 0.36-0.41 us inside the launches against 0.31 for the same step on register-resident words (bench.py `decode_rate`) —
+// with one step (256 KV bytes) in flight per wave a CU has <= 27 KB on its way, and at the ~1.5 us a load takes while the chip
+// streams 4-5 TB/s that is less than the four waves of a SIMD decode in the meantime (4 x 0.31 us): every step waited ~0.25 us.
+// (Round 3's ring experiments lost 10-19 %: they padded every wave's steps to whole rounds of three — up to 28 % more decode work
+// on the 7- and 8-step waves of gate | up — and issued the tail loads under branches.  Here nothing is padded, and steps past
+// the end request a dummy.)
+#ifndef QPAL_PREFETCH_DEPTH
+#define QPAL_PREFETCH_DEPTH 1
+#endif
 template <class Codec, bool XLDS, int NBG>
 __device__ __forceinline__ void gemv_run(uint32_t (&w)[Codec::NW], const uint32_t *lut, uint32_t laneoff,
                                          const StreamView &sv, const uint16_t *xg, const uint16_t *xs, int k, int n,
                                          int zero_off, int s0, int s1, int lane, Acc<NBG> &acc) {
+#if QPAL_PREFETCH_DEPTH == 2
+    if constexpr (NBG == 1) {
+        if (s0 >= s1) return;
+        uint32_t wb[Codec::NW], wc[Codec::NW];
+        load_step_w_or_dummy<Codec::NW>(sv, s0 + 1, s1, lane, wb);
+        for (int s = s0;; s += 3) {
+            {
+                load_step_w_or_dummy<Codec::NW>(sv, s + 2, s1, lane, wc);
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's decode (hipcc sinks it otherwise)
+                u32x4 xb[NBG][2];
+                load_step_x<XLDS, NBG>(sv, xg, xs, k, n, zero_off, s, lane, xb);
+                gemv_step<Codec, NBG>(lut, laneoff, w, xb, acc);
+            }
+            if (s + 1 >= s1) break;
+            {
+                load_step_w_or_dummy<Codec::NW>(sv, s + 3, s1, lane, w);
+                __builtin_amdgcn_sched_barrier(0);
+                u32x4 xb[NBG][2];
+                load_step_x<XLDS, NBG>(sv, xg, xs, k, n, zero_off, s + 1, lane, xb);
+                gemv_step<Codec, NBG>(lut, laneoff, wb, xb, acc);
+            }
+            if (s + 2 >= s1) break;
+            {
+                load_step_w_or_dummy<Codec::NW>(sv, s + 4, s1, lane, wb);
+                __builtin_amdgcn_sched_barrier(0);
+                u32x4 xb[NBG][2];
+                load_step_x<XLDS, NBG>(sv, xg, xs, k, n, zero_off, s + 2, lane, xb);
+                gemv_step<Codec, NBG>(lut, laneoff, wc, xb, acc);
+            }
+            if (s + 3 >= s1) break;
+        }
+        return;
+    }
+#endif
     uint32_t wb[Codec::NW];
     for (int s = s0; s < s1; s += 2) {
         {
@@ -682,11 +734,16 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     const int total_items = ie[kMaxJobs - 1];
     // Pin job 0's loads next to the item table's: left alone, the compiler requests job 0 only inside the loop, after
     // it has waited for the item table — two kernel-argument round trips on the critical path instead of one.
+    // (round 4: EVERYTHING the path to the first weight loads reads — the chunk partition, nsc2, x_lds, the prezero count — or it is
+    // a second, dependent round trip: the stamps had the arguments "in hand" 0.76 us after the wave's entry with two batches)
     asm volatile("" ::"s"(p.c1), "s"(p.c2), "s"(p.x), "s"(p.tab), "s"(p.nrows), "s"(p.nsc1), "s"(p.log2_wpr), "s"(p.sk),
-                 "s"(p.out), "s"(ie[0]), "s"(p.wscale), "s"(p.base2));
+                 "s"(p.out), "s"(ie[0]), "s"(p.wscale), "s"(p.base2), "s"(p.nsc2), "s"(p.nc1), "s"(p.base1), "s"(p.rem1), "s"(p.rem2),
+                 "s"(p.x_lds), "s"(p.n), "s"(p.k), "s"(mp.zero_chunks), "s"(p.ldo), "s"(p.accumulate),
+                 "s"(__builtin_bit_cast(uint32_t, p.oscale)));
     // One work item.  FIRST (this workgroup's first item, compile-time): the only one that consumes the early-staged registers —
-    // a body of its own, so that those registers are plain straight-line values: as values carried into a loop they were copied
-    // at the loop header, and the copy waits for the loads (round 4, see TcqCodec::raw).
+    // a body of its own, so that those registers are plain straight-line values.  (Measured against ONE body with the early wait
+    // in front of the item loop, profiles/r04_ab_prologue.txt: the single body is 0.3-0.4 us slower on every short launch —
+    // 900 vs 932 tok/s — although it is a third of the code: loop-carried copies of the staged registers, 120 instead of 91 VGPRs.)
     auto run_item = [&](const int gitem, auto first_c) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_c)::value;
         // (declared per item: as a capture of this lambda it ended up in scratch memory.  Two arrays, not a union: `on2` is
@@ -697,12 +754,18 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
             uint32_t a[C1::NW];
             uint32_t b[TWO ? CB::NW : 1];
         } w;
+        // Which job?  Most workgroups work on job 0: two scalar instructions for them instead of the branch-free scan of the whole
+        // table (~60 scalar instructions; round 4: the prologue is bound by instruction ISSUE — four waves per SIMD executing the
+        // same scalar code get an issue slot every ~16 cycles each, and ~200 instructions stood between a wave's entry and its
+        // first weight load: ~1 us of a 5-6 us launch)
         int j = 0, item_begin = 0;
+        if (gitem >= ie[0]) {
 #pragma unroll
-        for (int i = 0; i < kMaxJobs - 1; i++) {
-            if (gitem >= ie[i]) {
-                j = i + 1;
-                item_begin = ie[i];
+            for (int i = 0; i < kMaxJobs - 1; i++) {
+                if (gitem >= ie[i]) {
+                    j = i + 1;
+                    item_begin = ie[i];
+                }
             }
         }
         if (j != cur_j) {
@@ -718,12 +781,18 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         const int log2_rpw = LOG2W - p.log2_wpr;  // log2(rows per workgroup)
         const int zero_off = p.n * p.k;
         const bool x_lds = NBG == 1 && p.x_lds;
-        QPAL_STAMP(0);
+#ifdef QPAL_STAMPS  // stamp 0 (kernel arguments in hand) carries the time since the wave's first instruction in its bits 52..63
+        if (p.dbg && lane == 0 && FIRST) {
+            const unsigned long long t_now = __builtin_amdgcn_s_memrealtime();
+            p.dbg[((long)blockIdx.x * 16 + wave) * 8] = (t_now & ((1ull << 52) - 1)) | ((t_now - t_entry) << 52);
+        }
+#endif
 
         int rg = item, ks = 0;
-        if (p.sk > 1) {
-            rg = item / p.sk;
-            ks = item - rg * p.sk;
+        if (p.sk > 1) {  // (a power of two: plan_launch; a division is ~35 instructions here)
+            const int lsk = 31 - __builtin_clz((unsigned)p.sk);
+            rg = item >> lsk;
+            ks = item & (p.sk - 1);
         }
         // row slot rl of this workgroup -> supertile row (pair mode: sk == -1, see TcParams); everything recomputed where it is
         // used rather than kept in SGPRs across the steps
@@ -793,6 +862,10 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         // (empty) volatile asm, which orders its uses behind the wait.
         if constexpr (kEarly) {
             if (FIRST && early) {
+#ifdef QPAL_STAMPS  // (the stamp-0 store above is younger than the early loads and takes its time)
+                if (p.dbg) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else
+#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int r = 0; r < XR; r++) asm volatile("" : "+v"(exr[r]));
@@ -830,15 +903,6 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         if constexpr (kEarly) {
             if (FIRST && early) {  // early staging, part 2b: registers -> LDS
                 const int total = en * ek;
-#ifdef QPAL_STAMPS
-                if (p.dbg) {  // slot 2: the wave's first instruction; slot 3: the early x / table loads (older than the first weight loads) have landed
-                    const unsigned long long t_landed = __builtin_amdgcn_s_memrealtime();
-                    if (lane == 0) {
-                        p.dbg[((long)blockIdx.x * 16 + wave) * 8 + 2] = t_entry;
-                        p.dbg[((long)blockIdx.x * 16 + wave) * 8 + 3] = t_landed;
-                    }
-                }
-#endif
 #pragma unroll
                 for (int r = 0; r < XR; r++) {
                     const int i = tid * 8 + r * (NT * 8);

@@ -57,6 +57,7 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
         unsigned long long t0 = ~0ull, t7 = 0, t0max = 0, t7min = ~0ull;
         double ph[8] = {0}, phmax[8] = {0};
         int nw = 0;
+        for (int w = 0; w < grid * 16; w++) h[w * 8] &= (1ull << 52) - 1;  // (bits 52..63: time since the wave's entry, perf/stamps_replay.py)
         for (int w = 0; w < grid * 16; w++) {
             if (!h[w * 8] || !h[w * 8 + 7]) continue;  // wave of a narrower workgroup
             nw++;
