@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box A/B of library variants on the three figures of the default bench line: plain token, token behind the incoherence
 # wrapper, whole-model decode step.   bash perf/ab_wrap.sh "" _variant ...
-run() { QPAL_LIB=q-palette_amd/libqpal_hip$1.so timeout -k 10 400 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-kind-breakdown 2>/dev/null | python -c "
+run() { QPAL_LIB=q-palette_amd/libqpal_hip$1.so timeout -k 10 400 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-kind-breakdown --no-calibration 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

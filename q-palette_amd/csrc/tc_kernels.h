@@ -654,26 +654,80 @@ struct TcEarly {
     const uint16_t *x;  // shared by all jobs, staged in LDS
     const void *tab;    // shared codebook
     int n, k;           // x is [n][k]
-    int on;             // 0: jobs differ (or x does not fit LDS): everything comes from `mp` as before
+    int on;             // 0: jobs differ (or x does not fit LDS): everything comes from `mp` as before.  Bit 0: plain early staging.
+                        // Rotating launches (round 4): bit 1: every job rotates the same x (x_rot in {2, 4}: k = 2048 / 4096) with the
+                        // same sign vector / RMSNorm weight and shares the codebook — the rotation's inputs and the image's table
+                        // entries are requested at the wave's first instruction; bit 2: x is fp32; bit 3: RMSNorm in front of the rotation; bits 4..6: x_rot
+    const uint16_t *su;  // rotating launches: sign vector (or null), RMSNorm weight (or null)
+    const uint16_t *rw;
 };
 
 // host: the launch qualifies when x is staged in LDS and every job has the same x, codebook and batch
 inline TcEarly early_args(const TcMultiParams &mp) {
     const TcParams &a = mp.job[0];
     // (x and its 32-half zero pad must fit the chunks the threads hold)
-    TcEarly e{a.x, a.tab, a.n, a.k, a.x_lds && !a.x_rot && a.n <= 8 && a.n * a.k + 32 <= kEarlyXChunks * 64 * gemv_waves<1>() * 8 ? 1 : 0};
+    TcEarly e{a.x, a.tab, a.n, a.k, a.x_lds && !a.x_rot && a.n <= 8 && a.n * a.k + 32 <= kEarlyXChunks * 64 * gemv_waves<1>() * 8 ? 1 : 0,
+              a.x_su, a.x_rms_w};
+    if (a.x_lds && (a.x_rot == 2 || a.x_rot == 4) && a.n == 1) e.on = 2 | (a.x_src_f32 ? 4 : 0) | (a.x_rms_eps > 0.f ? 8 : 0) | (a.x_rot << 4);
     for (int j = 1; j < mp.njobs; j++) {
         const TcParams &b = mp.job[j];
-        if (b.x != a.x || b.tab != a.tab || b.n != a.n || b.k != a.k || !b.x_lds || b.x_rot) e.on = 0;
+        if (b.x != a.x || b.tab != a.tab || b.n != a.n || b.k != a.k || !b.x_lds || b.x_rot != a.x_rot || b.x_su != a.x_su ||
+            b.x_rms_w != a.x_rms_w || b.x_src_f32 != a.x_src_f32 || (b.x_rms_eps > 0.f) != (a.x_rms_eps > 0.f))
+            e.on = 0;
     }
     return e;
+}
+
+// Stage 1 of the rotation fused into the GEMV staging, on inputs that are already in registers (rq[kc]: x — two chunks when fp32 —,
+// RMSNorm weight, sign vector of this wave's row tile and 32-column half kc): conversion (RMSNorm fused: the transform is linear,
+// so the norm's scalar 1/rms is applied AFTER it — stage 1 rotates x * w * 2^-6, the power of two keeps fp16 clear of overflow on
+// residual-stream outliers — while the same lanes sum the squares of what they hold), sign flip, the four column tiles of
+// x_tile . H_64 (8 MFMAs) into d1buf, the wave's sum of squares into part[wave].
+constexpr float kRmsPre = 0.015625f;
+__device__ __forceinline__ void rot_stage1_regs(const u32x4 (&rq)[2][4], bool f32, bool rms, bool has_w, bool has_su, int wave, int lane,
+                                                wht_float4 *d1buf, float *part) {
+    float ss = 0.f;
+    wht_half8 a[2];
+#pragma unroll
+    for (int kc = 0; kc < 2; kc++) {
+        wht_half8 h;
+        if (f32 || rms) {
+            float f[8];
+            if (f32) {
+                const float4_t v0 = __builtin_bit_cast(float4_t, rq[kc][0]), v1 = __builtin_bit_cast(float4_t, rq[kc][1]);
+#pragma unroll
+                for (int e = 0; e < 4; e++) { f[e] = v0[e]; f[4 + e] = v1[e]; }
+            } else {
+                const wht_half8 hx = __builtin_bit_cast(wht_half8, rq[kc][0]);
+#pragma unroll
+                for (int e = 0; e < 8; e++) f[e] = (float)hx[e];
+            }
+            const wht_half8 wgt = __builtin_bit_cast(wht_half8, rq[kc][2]);
+            const float pre = rms ? kRmsPre : 1.0f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                ss += f[e] * f[e];
+                h[e] = (_Float16)(f[e] * pre * (has_w ? (float)wgt[e] : 1.0f));
+            }
+        } else {
+            h = __builtin_bit_cast(wht_half8, rq[kc][0]);
+        }
+        if (has_su) h = h * __builtin_bit_cast(wht_half8, rq[kc][3]);
+        a[kc] = h;
+    }
+    wht64_wg_stage1_pre(wave, lane, d1buf, a[0], a[1]);
+    if (rms) {
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+        if (lane == 0) part[wave] = ss;
+    }
 }
 
 // ROT: 0 plain; 1: can rotate x while staging it (k = 2048 / 4096, wht64.h); 2: the 14336-wide rotation of rot_k28.h (its own
 // instantiation: its registers would make the other rotating launches spill); 3: plain + pair mode (TcParams: sk == -1)
 template <class C1, class C2, int NBG, int ROT = 0>
 __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const void *etab, int en, int ek, int eon,
-                                                       const TcMultiParams mp) {
+                                                       const uint16_t *esu, const uint16_t *erw, const TcMultiParams mp) {
     constexpr bool TWO = !std::is_void_v<C2>;
     using CB = std::conditional_t<TWO, C2, C1>;
     constexpr int W = gemv_waves<NBG>(), LOG2W = W == 16 ? 4 : 3, NT = 64 * W;
@@ -705,7 +759,66 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     constexpr int XR = kEarlyXChunks;    // 16-byte chunks of x a thread holds likewise
     [[maybe_unused]] u32x4 exr[XR];
     [[maybe_unused]] uint32_t etv[EV][C1::RAWN];
-    const bool early = kEarly && eon != 0;
+    const bool early = kEarly && (eon & 1) != 0;
+    // Rotating launches (ROT == 1), early part: wave t < x_rot requests its row tile of the rotation's inputs, the other waves the
+    // table entries of the codebook image they will build — all of it at the wave's first instruction from preloaded arguments,
+    // from inline asm (see part 2a below).  Everything is in by the time the kernel arguments are (~0.3 us), i.e. BEFORE the
+    // first weights can be requested at all: the weight stream — 6.8 MB for the first step of 4 096 waves, a microsecond of the
+    // chip's bandwidth and the launch's critical path — starts against an idle memory system and nothing later competes with it.
+    // (What round 3 and the first half of round 4 found again and again: every way of making the rotation's or the image's loads
+    // "faster" that put them beside or in front of the weight stream made the token slower.)
+    constexpr int kRotTab = 6;  // table entries a builder thread holds: 4 096 chunks over 1 024 - 64 x_rot threads
+#ifndef QPAL_ROT_TAB_EARLY
+#define QPAL_ROT_TAB_EARLY 1
+#endif
+    constexpr bool kRotTabEarly = QPAL_ROT_TAB_EARLY != 0;  // (6 more registers held across the prologue: spills in most instantiations)
+    [[maybe_unused]] u32x4 rq_e[2][4];  // per 32-column half kc: x (two chunks when fp32), RMSNorm weight, sign vector
+    [[maybe_unused]] uint32_t rtv[kRotTab][C1::RAWN];
+    // (not for the widest two-stream codecs — 8 | 9 and 9 | 10 dwords per lane: their first weight step and the early registers
+    // together spill)
+    constexpr bool kRotEarly = ROT == 1 && NBG == 1 && C1::CHUNKS <= kRotTab * (1024 - 64 * 4) && C1::NW + (TWO ? CB::NW : 0) <= 15;
+    [[maybe_unused]] const bool rot_early = kRotEarly && (eon & 2) != 0;
+    [[maybe_unused]] const int e_rot = (eon >> 4) & 7;
+    if constexpr (kRotEarly) {
+        if (rot_early) {
+            if (wave < e_rot) {
+#pragma unroll
+                for (int kc = 0; kc < 2; kc++) {
+                    const uint32_t el = (uint32_t)((16 * wave + (lane & 15)) * 64 + 32 * kc + 8 * (lane >> 4));
+                    if (eon & 4) {
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rq_e[kc][0]) : "v"(el * 4u), "s"(ex));
+                        asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(rq_e[kc][1]) : "v"(el * 4u), "s"(ex));
+                    } else {
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rq_e[kc][0]) : "v"(el * 2u), "s"(ex));
+                    }
+                    if (erw) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rq_e[kc][2]) : "v"(el * 2u), "s"(erw));
+                    if (esu) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rq_e[kc][3]) : "v"(el * 2u), "s"(esu));
+                }
+                // ... and stage 1 of the rotation at once, BEFORE the kernel arguments are looked at: everything it needs is
+                // preloaded (n, k: where the staging area lies; the flags), its inputs land ~0.25 us from now, and its ~150
+                // instructions are then off the path between "kernel arguments in hand" and "first weights requested" — the
+                // three builder waves of this SIMD request their weights meanwhile, this wave a little later (its weights are
+                // not needed before stage 2 and the barrier behind it are done anyway)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int kc = 0; kc < 2; kc++) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) asm volatile("" : "+v"(rq_e[kc][q]));
+                }
+                uint16_t *xs_e = reinterpret_cast<uint16_t *>(scratch + W * 32 * 4 * en);
+                wht_float4 *d1buf_e = reinterpret_cast<wht_float4 *>(xs_e + ((en * ek + 32 + 7) & ~7));
+                rot_stage1_regs(rq_e, (eon & 4) != 0, (eon & 8) != 0, erw != nullptr, esu != nullptr, wave, lane, d1buf_e,
+                                reinterpret_cast<float *>(d1buf_e + 4 * 4 * 64));
+            } else if constexpr (kRotTabEarly) {
+                const int bt = tid - 64 * e_rot, nb = 1024 - 64 * e_rot;
+#pragma unroll
+                for (int r = 0; r < kRotTab; r++) {
+                    const int c = bt + r * nb;
+                    C1::raw_issue(etab, ((c < C1::CHUNKS ? c : 0) * 4) >> C1::LOG2C, rtv[r]);
+                }
+            }
+        }
+    }
     if constexpr (kEarly) {
         // Nothing in this block may USE what it loads (round 4): a use makes the compiler wait for the loads right here, in front of
         // the kernel-argument fetch below and of the first weight loads behind that — the round trips this block exists to overlap.
@@ -846,13 +959,6 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         const StreamView sv1{p.c1 + (long)(live ? sr : 0) * p.nsc1 * 16 * nw1, p.nsc1, 0};
         const StreamView sv2{two_rt ? p.c2 + (long)(live ? sr : 0) * p.nsc2 * 16 * nw2 : p.c1, two_rt ? p.nsc2 : p.nsc1,
                              p.col2};
-        Acc<NBG> acc;
-        static_for<0, NBG>([&](auto bc) {
-            static_for<0, 4>([&](auto ac) {
-                acc.v[decltype(bc)::value][decltype(ac)::value] = float4_t{0.f, 0.f, 0.f, 0.f};
-            });
-        });
-
         // Early staging, part 2a: the early loads were issued from inline asm, i.e. outside the compiler's wait-count bookkeeping —
         // wait for them by hand, HERE: ~0.2-0.3 us after the wave's entry they and the kernel arguments have arrived together
         // (perf/first_touch.hip), and from here on every load in flight is one the compiler knows about.  (Requesting the weights
@@ -860,6 +966,22 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         // hidden loads from the compiler's own, and the hazard waits the compiler puts between the two typed weight-load branches
         // then wait for the early loads anyway, at points no source change moved.)  Every early value then passes through an
         // (empty) volatile asm, which orders its uses behind the wait.
+        if constexpr (kRotEarly) {
+            if (FIRST && rot_early) {  // the rotation's inputs / the image's table entries, requested at the wave's first instruction
+#ifdef QPAL_STAMPS
+                if (p.dbg) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else
+#endif
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (kRotTabEarly) {
+#pragma unroll
+                    for (int r = 0; r < kRotTab; r++) {
+#pragma unroll
+                        for (int q = 0; q < C1::RAWN; q++) asm volatile("" : "+v"(rtv[r][q]));
+                    }
+                }
+            }
+        }
         if constexpr (kEarly) {
             if (FIRST && early) {
 #ifdef QPAL_STAMPS  // (the stamp-0 store above is younger than the early loads and takes its time)
@@ -958,54 +1080,74 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                     // sum the squares of what they load; the sums meet at the barrier the transform has anyway.  x is read
                     // once and no wave waits for the norm before the matrix pipe starts.
                     const bool rms = p.x_rms_eps > 0.f;
-                    constexpr float kRmsPre = 0.015625f;
-                    float ss = 0.f;
                     float *part = reinterpret_cast<float *>(d1buf + 4 * 4 * 64);
-                    auto load_row = [&](const uint16_t *xrow) {
-                        return [=, &ss](int t, int kc) {
-                            const int off = (16 * t + (lane & 15)) * 64 + 32 * kc + 8 * (lane >> 4);
-                            wht_half8 h;
-                            if (p.x_src_f32 || rms) {
-                                float f[8];
-                                if (p.x_src_f32) {
-                                    const float *xf = reinterpret_cast<const float *>(xrow) + off;
-                                    const float4_t v0 = *reinterpret_cast<const float4_t *>(xf), v1 = *reinterpret_cast<const float4_t *>(xf + 4);
-#pragma unroll
-                                    for (int e = 0; e < 4; e++) { f[e] = v0[e]; f[4 + e] = v1[e]; }
-                                } else {
-                                    const wht_half8 hx = *reinterpret_cast<const wht_half8 *>(xrow + off);
-#pragma unroll
-                                    for (int e = 0; e < 8; e++) f[e] = (float)hx[e];
-                                }
-                                wht_half8 wgt;
-                                if (p.x_rms_w) wgt = *reinterpret_cast<const wht_half8 *>(p.x_rms_w + off);
-                                const float pre = rms ? kRmsPre : 1.0f;
-#pragma unroll
-                                for (int e = 0; e < 8; e++) {
-                                    ss += f[e] * f[e];
-                                    h[e] = (_Float16)(f[e] * pre * (p.x_rms_w ? (float)wgt[e] : 1.0f));
-                                }
-                            } else {
-                                h = *reinterpret_cast<const wht_half8 *>(xrow + off);
-                            }
-                            if (p.x_su) h = h * *reinterpret_cast<const wht_half8 *>(p.x_su + off);
-                            return h;
-                        };
-                    };
                     // Batch 1 only (the host refuses x_rot otherwise): the transform is spread over all 16 waves in two
                     // stages around one extra barrier — x is read once per workgroup and no wave runs more than ~100
                     // instructions; the codebook image is built by the waves that have no stage-1 tile.
                     // (Alternatives measured slower: one wave quad rotating straight from global memory, +2.0 us per
                     // launch; x * su staged in LDS first, two more barriers.)
-                    if (p.x_rot == 4) wht64_wg_stage1<4>(wave, lane, d1buf, load_row(p.x));
-                    else wht64_wg_stage1<2>(wave, lane, d1buf, load_row(p.x));
-                    if (rms && wave < p.x_rot) {
+                    // Stage 1: done at the wave's first instructions when the launch qualified (rot_early: kernel top); otherwise
+                    // here, with loads on demand (every load a round trip of its own: the compiler waits on the spot — the slow path)
+                    bool stage1_done = false;
+                    if constexpr (kRotEarly) stage1_done = FIRST && rot_early;
+                    if (!stage1_done) {
+                        float ss = 0.f;
+                        auto load_row = [&](const uint16_t *xrow) {
+                            return [=, &ss](int t, int kc) {
+                                const int off = (16 * t + (lane & 15)) * 64 + 32 * kc + 8 * (lane >> 4);
+                                wht_half8 h;
+                                if (p.x_src_f32 || rms) {
+                                    float f[8];
+                                    if (p.x_src_f32) {
+                                        const float *xf = reinterpret_cast<const float *>(xrow) + off;
+                                        const float4_t v0 = *reinterpret_cast<const float4_t *>(xf), v1 = *reinterpret_cast<const float4_t *>(xf + 4);
 #pragma unroll
-                        for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
-                        if (lane == 0) part[wave] = ss;
+                                        for (int e = 0; e < 4; e++) { f[e] = v0[e]; f[4 + e] = v1[e]; }
+                                    } else {
+                                        const wht_half8 hx = *reinterpret_cast<const wht_half8 *>(xrow + off);
+#pragma unroll
+                                        for (int e = 0; e < 8; e++) f[e] = (float)hx[e];
+                                    }
+                                    wht_half8 wgt;
+                                    if (p.x_rms_w) wgt = *reinterpret_cast<const wht_half8 *>(p.x_rms_w + off);
+                                    const float pre = rms ? kRmsPre : 1.0f;
+#pragma unroll
+                                    for (int e = 0; e < 8; e++) {
+                                        ss += f[e] * f[e];
+                                        h[e] = (_Float16)(f[e] * pre * (p.x_rms_w ? (float)wgt[e] : 1.0f));
+                                    }
+                                } else {
+                                    h = *reinterpret_cast<const wht_half8 *>(xrow + off);
+                                }
+                                if (p.x_su) h = h * *reinterpret_cast<const wht_half8 *>(p.x_su + off);
+                                return h;
+                            };
+                        };
+                        if (p.x_rot == 4) wht64_wg_stage1<4>(wave, lane, d1buf, load_row(p.x));
+                        else wht64_wg_stage1<2>(wave, lane, d1buf, load_row(p.x));
+                        if (rms && wave < p.x_rot) {
+#pragma unroll
+                            for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+                            if (lane == 0) part[wave] = ss;
+                        }
                     }
                     if (p.tab != cur_tab) {
-                        if (wave >= p.x_rot) C1::template build<QPAL_ROT_BUILD_U>(lut, p.tab, tid - 64 * p.x_rot, 1024 - 64 * p.x_rot);
+                        bool built = false;
+                        if constexpr (kRotEarly && kRotTabEarly) {
+                            if (FIRST && rot_early) {  // (host: every job of the launch has job 0's codebook)
+                                if (wave >= p.x_rot) {
+                                    const int bt = tid - 64 * p.x_rot, nb = 1024 - 64 * p.x_rot;
+#pragma unroll
+                                    for (int r = 0; r < kRotTab; r++) {
+                                        const int c = bt + r * nb;
+                                        const uint32_t v = C1::fix(rtv[r], ((c < C1::CHUNKS ? c : 0) * 4) >> C1::LOG2C);
+                                        if (c < C1::CHUNKS) reinterpret_cast<u32x4 *>(lut)[c] = u32x4{v, v, v, v};
+                                    }
+                                }
+                                built = true;
+                            }
+                        }
+                        if (!built && wave >= p.x_rot) C1::template build<QPAL_ROT_BUILD_U>(lut, p.tab, tid - 64 * p.x_rot, 1024 - 64 * p.x_rot);
                         cur_tab = p.tab;
                     }
                     if (tid < 32) xs[total + tid] = 0;
@@ -1052,6 +1194,12 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
             __syncthreads();
         }
         QPAL_STAMP(3);
+        Acc<NBG> acc;  // (zeroed here, not in front of the staging: 16 registers the rotating prologue has other uses for)
+        static_for<0, NBG>([&](auto bc) {
+            static_for<0, 4>([&](auto ac) {
+                acc.v[decltype(bc)::value][decltype(ac)::value] = float4_t{0.f, 0.f, 0.f, 0.f};
+            });
+        });
         if constexpr (ANY) {
             if constexpr (is_mix_v<C1>) {
                 if (lut_job)

@@ -6,9 +6,9 @@ namespace qpal {
 
 int launch_tcq_gemv_any(const TcMultiParams &p, int S, int grid, hipStream_t stream) {
     const TcEarly e = early_args(p);
-    if (S == 9) hipLaunchKernelGGL((tc_gemv_kernel<TcqAny<9>, void, 1, false>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, p);
-    else if (S == 10) hipLaunchKernelGGL((tc_gemv_kernel<TcqAny<10>, void, 1, false>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, p);
-    else if (S == 11) hipLaunchKernelGGL((tc_gemv_kernel<TcqAny<11>, void, 1, false>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, p);
+    if (S == 9) hipLaunchKernelGGL((tc_gemv_kernel<TcqAny<9>, void, 1, false>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.su, e.rw, p);
+    else if (S == 10) hipLaunchKernelGGL((tc_gemv_kernel<TcqAny<10>, void, 1, false>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.su, e.rw, p);
+    else if (S == 11) hipLaunchKernelGGL((tc_gemv_kernel<TcqAny<11>, void, 1, false>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.su, e.rw, p);
     else return QPAL_E_PARAM;
     return (int)hipGetLastError();
 }

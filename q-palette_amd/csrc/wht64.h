@@ -164,6 +164,23 @@ __device__ __forceinline__ void wht64_wg_stage1(int wave, int lane, wht_float4 *
     }
 }
 
+// stage 1 on a row tile the caller has already loaded (a0 / a1: the two 32-column halves as A fragments)
+__device__ __forceinline__ void wht64_wg_stage1_pre(int wave, int lane, wht_float4 *d1buf, wht_half8 a0, wht_half8 a1) {
+    const uint32_t q = lane >> 4, j = lane & 15;
+    uint32_t neg = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < 8; e++) neg |= wht_parity(e & (j & 7u)) << e;
+    const u32x4 base = wht_signs(neg);
+#pragma unroll
+    for (uint32_t ct = 0; ct < 4; ct++) {
+        const uint32_t f0 = ((q & 1u) & (j >> 3)) ^ ((q >> 1) & (ct & 1u)), f1 = f0 ^ ((ct >> 1) & 1u);
+        wht_float4 acc{0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, __builtin_bit_cast(wht_half8, wht_flip(base, f0, f0)), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(wht_half8, wht_flip(base, f1, f1)), acc, 0, 0, 0);
+        d1buf[(wave * 4 + ct) * 64 + lane] = acc;
+    }
+}
+
 template <int RT, class Store>
 __device__ __forceinline__ void wht64_wg_stage2(int wave, int lane, float scale, const wht_float4 *d1buf, Store &&store) {
     if (wave >= 4 * RT) return;
