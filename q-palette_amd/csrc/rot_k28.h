@@ -28,14 +28,65 @@ constexpr int kTbRow = 80;                                 // bytes per column r
 // Contains two workgroup barriers; the caller adds the one after the image is in place.
 // after_loads(): called by every wave once its own global loads are out (the place for the caller's less urgent requests: a
 // burst of table reads in FRONT of the x loads delays the whole chain — tc_kernels.h build_image)
+// The rotation's global inputs as one wave holds them (round 4: requested at the wave's first instruction from preloaded kernel
+// arguments, from inline asm — tc_kernels.h — so that they are in before the first weights are requested and no wait for them
+// waits for the weight stream; the codebook image's table entries likewise, by the caller).
+struct RotK28Regs {
+    u32x2 hk01, hk23;   // stage B's A operand (hadk row pieces; garbage where the row / piece does not exist: rot_k28_regs zeroes)
+    u32x4 a0, a1;       // stage A: the two 32-column halves of this lane's row of the [224][64] view
+    u32x4 s0, s1;       // the sign vector likewise (when there is one)
+};
+__device__ __forceinline__ void rot_k28_issue(RotK28Regs &r, const uint16_t *x, const uint16_t *su, const uint16_t *hadk, int wave, int lane) {
+    const uint32_t q = lane >> 4, j = lane & 15;
+    const int jrow = 16 * (wave & 1) + (int)j;
+    const uint32_t hoff = (uint32_t)(((jrow < kK28 ? jrow : 0) * kK28 + 8 * (int)q) * 2);
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r.hk01) : "v"(hoff), "s"(hadk));
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r.hk23) : "v"(q < 3 ? hoff + 8u : hoff), "s"(hadk));
+    if (wave < 14) {
+        const uint32_t off0 = (uint32_t)(((16 * wave + (int)j) * 64 + 8 * (int)q) * 2);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.a0) : "v"(off0), "s"(x));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(r.a1) : "v"(off0), "s"(x));
+        if (su) {
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.s0) : "v"(off0), "s"(su));
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(r.s1) : "v"(off0), "s"(su));
+        }
+    }
+}
+// every value of `r` passes through an empty volatile asm: its uses are ordered behind the caller's wait
+__device__ __forceinline__ void rot_k28_landed(RotK28Regs &r) {
+    asm volatile("" : "+v"(r.hk01), "+v"(r.hk23), "+v"(r.a0), "+v"(r.a1), "+v"(r.s0), "+v"(r.s1));
+}
+
+template <bool PRE, class XsIndex, class AfterLoads>
+__device__ __forceinline__ void rot_k28_impl(const RotK28Regs &pre_regs, bool has_su, const uint16_t *x, const uint16_t *su, const uint16_t *hadk, float pre,
+                                             float post, uint16_t *xs, unsigned char *tb, int wave, int lane, XsIndex &&xs_idx, AfterLoads &&after_loads);
+
 template <class XsIndex, class AfterLoads>
 __device__ __forceinline__ void rot_k28(const uint16_t *x, const uint16_t *su, const uint16_t *hadk, float pre, float post,
                                         uint16_t *xs, unsigned char *tb, int wave, int lane, XsIndex &&xs_idx, AfterLoads &&after_loads) {
+    const RotK28Regs none{};
+    rot_k28_impl<false>(none, su != nullptr, x, su, hadk, pre, post, xs, tb, wave, lane, xs_idx, after_loads);
+}
+// the same on inputs that are already in registers (has_su: whether r.s0 / r.s1 hold a sign vector)
+template <class XsIndex>
+__device__ __forceinline__ void rot_k28_regs(const RotK28Regs &r, bool has_su, float pre, float post, uint16_t *xs, unsigned char *tb, int wave,
+                                             int lane, XsIndex &&xs_idx) {
+    rot_k28_impl<true>(r, has_su, nullptr, nullptr, nullptr, pre, post, xs, tb, wave, lane, xs_idx, [] {});
+}
+
+template <bool PRE, class XsIndex, class AfterLoads>
+__device__ __forceinline__ void rot_k28_impl(const RotK28Regs &pre_regs, bool has_su, const uint16_t *x, const uint16_t *su, const uint16_t *hadk, float pre,
+                                             float post, uint16_t *xs, unsigned char *tb, int wave, int lane, XsIndex &&xs_idx, AfterLoads &&after_loads) {
     const uint32_t q = lane >> 4, j = lane & 15;
     // ---- stage B's A operand: hadk[16 (wave & 1) + j][8 q + e], zero outside 28 x 28; requested now, used after the barrier
     const int jrow = 16 * (wave & 1) + (int)j;
     u32x2 hk01{0u, 0u}, hk23{0u, 0u};  // a row is 28 halves = 56 bytes: 8-byte pieces; the piece at i = 28..31 is the next row's: zero
-    if (jrow < kK28) {
+    if constexpr (PRE) {
+        if (jrow < kK28) {
+            hk01 = pre_regs.hk01;
+            if (q < 3) hk23 = pre_regs.hk23;
+        }
+    } else if (jrow < kK28) {
         const gptr<const uint16_t> row = as_global(hadk) + jrow * kK28 + 8 * (int)q;
         hk01 = *(gptr<const u32x2>)(row);
         if (q < 3) hk23 = *(gptr<const u32x2>)(row + 4);
@@ -43,15 +94,22 @@ __device__ __forceinline__ void rot_k28(const uint16_t *x, const uint16_t *su, c
     // ---- stage A
     if (wave < 14) {
         const int off0 = (16 * wave + (int)j) * 64 + 8 * (int)q;  // row (16 wave + j) of the [224][64] view, k slots 8 q ..
-        wht_half8 a0 = *reinterpret_cast<const wht_half8 *>(x + off0);
-        wht_half8 a1 = *reinterpret_cast<const wht_half8 *>(x + off0 + 32);
-        wht_half8 s0v, s1v;
-        if (su) {
-            s0v = *reinterpret_cast<const wht_half8 *>(su + off0);
-            s1v = *reinterpret_cast<const wht_half8 *>(su + off0 + 32);
+        wht_half8 a0, a1, s0v, s1v;
+        if constexpr (PRE) {
+            a0 = __builtin_bit_cast(wht_half8, pre_regs.a0);
+            a1 = __builtin_bit_cast(wht_half8, pre_regs.a1);
+            s0v = __builtin_bit_cast(wht_half8, pre_regs.s0);
+            s1v = __builtin_bit_cast(wht_half8, pre_regs.s1);
+        } else {
+            a0 = *reinterpret_cast<const wht_half8 *>(x + off0);
+            a1 = *reinterpret_cast<const wht_half8 *>(x + off0 + 32);
+            if (has_su) {
+                s0v = *reinterpret_cast<const wht_half8 *>(su + off0);
+                s1v = *reinterpret_cast<const wht_half8 *>(su + off0 + 32);
+            }
         }
         after_loads();
-        if (su) {
+        if (has_su) {
             a0 = a0 * s0v;
             a1 = a1 * s1v;
         }

@@ -658,8 +658,9 @@ struct TcEarly {
                         // Rotating launches (round 4): bit 1: every job rotates the same x (x_rot in {2, 4}: k = 2048 / 4096) with the
                         // same sign vector / RMSNorm weight and shares the codebook — the rotation's inputs and the image's table
                         // entries are requested at the wave's first instruction; bit 2: x is fp32; bit 3: RMSNorm in front of the rotation; bits 4..6: x_rot
-    const uint16_t *su;  // rotating launches: sign vector (or null), RMSNorm weight (or null)
+    const uint16_t *su;  // rotating launches: sign vector (or null), RMSNorm weight (or null; the 14336-wide rotation: its hadK factor)
     const uint16_t *rw;
+    float pre, post;     // the 14336-wide rotation: x_pre, x_post
 };
 
 // host: the launch qualifies when x is staged in LDS and every job has the same x, codebook and batch
@@ -667,12 +668,17 @@ inline TcEarly early_args(const TcMultiParams &mp) {
     const TcParams &a = mp.job[0];
     // (x and its 32-half zero pad must fit the chunks the threads hold)
     TcEarly e{a.x, a.tab, a.n, a.k, a.x_lds && !a.x_rot && a.n <= 8 && a.n * a.k + 32 <= kEarlyXChunks * 64 * gemv_waves<1>() * 8 ? 1 : 0,
-              a.x_su, a.x_rms_w};
+              a.x_su, a.x_rms_w, a.x_pre, a.x_post};
+    if (a.x_lds && a.x_rot == kK28 && a.n == 1 && a.x_hadk && !a.x_src_f32 && !(a.x_rms_eps > 0.f)) {  // bit 1 with x_rot = 28 in bits 4..9
+        e.on = 2 | (kK28 << 4);
+        e.rw = a.x_hadk;
+    }
     if (a.x_lds && (a.x_rot == 2 || a.x_rot == 4) && a.n == 1) e.on = 2 | (a.x_src_f32 ? 4 : 0) | (a.x_rms_eps > 0.f ? 8 : 0) | (a.x_rot << 4);
     for (int j = 1; j < mp.njobs; j++) {
         const TcParams &b = mp.job[j];
         if (b.x != a.x || b.tab != a.tab || b.n != a.n || b.k != a.k || !b.x_lds || b.x_rot != a.x_rot || b.x_su != a.x_su ||
-            b.x_rms_w != a.x_rms_w || b.x_src_f32 != a.x_src_f32 || (b.x_rms_eps > 0.f) != (a.x_rms_eps > 0.f))
+            b.x_rms_w != a.x_rms_w || b.x_src_f32 != a.x_src_f32 || (b.x_rms_eps > 0.f) != (a.x_rms_eps > 0.f) || b.x_hadk != a.x_hadk ||
+            b.x_pre != a.x_pre || b.x_post != a.x_post)
             e.on = 0;
     }
     return e;
@@ -778,7 +784,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     // together spill)
     constexpr bool kRotEarly = ROT == 1 && NBG == 1 && C1::CHUNKS <= kRotTab * (1024 - 64 * 4) && C1::NW + (TWO ? CB::NW : 0) <= 15;
     [[maybe_unused]] const bool rot_early = kRotEarly && (eon & 2) != 0;
-    [[maybe_unused]] const int e_rot = (eon >> 4) & 7;
+    [[maybe_unused]] const int e_rot = (eon >> 4) & 63;
     if constexpr (kRotEarly) {
         if (rot_early) {
             if (wave < e_rot) {
@@ -837,6 +843,22 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                 const int c = tid + r * NT;
                 C1::raw_issue(etab, ((c < C1::CHUNKS ? c : 0) * 4) >> C1::LOG2C, etv[r]);
             }
+        }
+    }
+    // The 14336-wide rotation (ROT == 2, down_proj behind the wrapper) likewise: this wave's pieces of hadK, of x and of the sign
+    // vector, and the image's table entries (the rotation's scratch aliases the image: they are written after stage B), all
+    // requested now.  Round 3's version requested them inside the item, BEHIND the first weights: vector-memory operations complete
+    // in issue order, so the rotation could not start before the first weight step of the wave had landed (+2.8 us per launch
+    // against the plain kernel).
+    constexpr bool kRot28Early = ROT == 2 && NBG == 1 && C1::LDS_DWORDS * 4 >= kP28 * kTbRow && C1::CHUNKS <= 4 * 1024;
+    [[maybe_unused]] const bool rot28_early = kRot28Early && (eon & 2) != 0 && e_rot == kK28;
+    [[maybe_unused]] RotK28Regs r28;
+    [[maybe_unused]] uint32_t ev28[4][C1::RAWN];
+    if constexpr (kRot28Early) {
+        if (rot28_early) {
+            rot_k28_issue(r28, ex, esu, erw, wave, lane);
+#pragma unroll
+            for (int r = 0; r < C1::CHUNKS / 1024; r++) C1::raw_issue(etab, ((tid + r * 1024) * 4) >> C1::LOG2C, ev28[r]);
         }
     }
     // one scalar-load round trip for everything the first item needs: the item table and job 0
@@ -982,6 +1004,21 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                 }
             }
         }
+        if constexpr (kRot28Early) {
+            if (FIRST && rot28_early) {
+#ifdef QPAL_STAMPS
+                if (p.dbg) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else
+#endif
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                rot_k28_landed(r28);
+#pragma unroll
+                for (int r = 0; r < C1::CHUNKS / 1024; r++) {
+#pragma unroll
+                    for (int q = 0; q < C1::RAWN; q++) asm volatile("" : "+v"(ev28[r][q]));
+                }
+            }
+        }
         if constexpr (kEarly) {
             if (FIRST && early) {
 #ifdef QPAL_STAMPS  // (the stamp-0 store above is younger than the early loads and takes its time)
@@ -1060,6 +1097,16 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                     // scratch alias the codebook image, whose table entries are requested first and written afterwards
                     constexpr int NVR = C1::CHUNKS / 1024;
                     uint32_t ev[NVR];
+                    bool from_regs = false;
+                    if constexpr (kRot28Early) from_regs = FIRST && rot28_early;
+                    if (from_regs) {
+                        if constexpr (kRot28Early) {
+                            rot_k28_regs(r28, p.x_su != nullptr, p.x_pre, p.x_post, xs, reinterpret_cast<unsigned char *>(lut), wave, lane,
+                                         [](int i) { return xs_index(i); });
+#pragma unroll
+                            for (int r = 0; r < NVR; r++) ev[r] = C1::fix(ev28[r], ((tid + r * 1024) * 4) >> C1::LOG2C);
+                        }
+                    } else
                     rot_k28(p.x, p.x_su, p.x_hadk, p.x_pre, p.x_post, xs, reinterpret_cast<unsigned char *>(lut), wave, lane,
                             [](int i) { return xs_index(i); }, [&] {
 #pragma unroll
