@@ -313,13 +313,18 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
     # Batch 1..3, multi-job launches: the harness owns the outputs here too — one block per launch, zeroed by the launch before it
     # (prezero), so that the library may share rows between workgroups (pair mode) or split K wherever that fills the chip,
     # without a memset node of its own.  The first launch of a token has no predecessor: its outputs are not declared zeroed.
+    # (Round 4: per GROUP — a mixed-scheme model's groups of tensor-core-order layers get owned, pre-zeroed outputs although other
+    # groups of the model are SIMT-packed: their single-codec gate | up launches then pair like the uniform model's.)
     owned = None
     if launch in ("multi", "chain") and parts is None and not batched and not no_prezero and \
-            all(n <= m.max_fused_batch and type(m) in qp.linear._PACKED_KEYS for groups in layers for grp in groups for m, _, _ in grp):
+            all(n <= m.max_fused_batch for groups in layers for grp in groups for m, _, _ in grp):
         owned = []
         for groups in layers:
             per = []
             for grp in groups:
+                if not all(type(m) in qp.linear._PACKED_KEYS for m, _, _ in grp):
+                    per.append(None)  # a SIMT-packed layer in the group: its op allocates its own fp16 output
+                    continue
                 ms = [m.out_features for m, _, _ in grp]
                 flat = torch.empty(n * sum(ms), dtype=torch.float32, device=device)
                 views, off = [], 0
@@ -328,6 +333,8 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
                     off += n * m_
                 per.append((flat, views))
             owned.append(per)
+        if all(g is None for per in owned for g in per):
+            owned = None
 
     def token():
         if parts is not None:
@@ -341,11 +348,18 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
             pre = {}  # group index -> output buffer zeroed by an earlier launch of this block
             for gi, grp in enumerate(groups):
                 if owned is not None:
-                    flat, views = owned[li][gi]
                     nli, ngi = (li, gi + 1) if gi < 3 else (li + 1, 0)
-                    nxt = owned[nli][ngi][0] if nli < len(layers) else None
+                    nxt = owned[nli][ngi][0] if nli < len(layers) and owned[nli][ngi] is not None else None
+                    pli, pgi = (li, gi - 1) if gi > 0 else (li - 1, 3)
+                    # this group's block was zeroed by the launch before it iff that launch was a multi-job launch of packed layers
+                    prev_zeroed = pli >= 0 and owned[pli][pgi] is not None
+                    if owned[li][gi] is None:  # a SIMT-packed layer in the group: plain launches (nothing zeroes the next block)
+                        if only_kind is None or only_kind == gi:
+                            outs += qp.multi_gemv([m for m, _, _ in grp], xs[grp[0][1]])
+                        continue
+                    flat, views = owned[li][gi]
                     if only_kind is None or only_kind == gi:
-                        ys = qp.multi_gemv([m for m, _, _ in grp], xs[grp[0][1]], outs=views, outs_zeroed=(li, gi) != (0, 0), prezero=nxt)
+                        ys = qp.multi_gemv([m for m, _, _ in grp], xs[grp[0][1]], outs=views, outs_zeroed=prev_zeroed, prezero=nxt)
                         # row-sharded model (--parallel tp, tp_70b): the outputs of o_proj / down_proj feed full-width consumers
                         # (the next block's rotation): all-gather them.  q|k|v stay head-sharded through attention, gate|up
                         # channel-sharded into down_proj.  A shard has 1 / N of the rows: with its outputs owned

@@ -593,7 +593,7 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         if (rc) return rc;
         return launch_tcq_gemm(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, nbg_of(rows), grid, s);
     }
-    bool plain = !mixed && nbg == 1;  // pair mode: the plain TCQ kernels of one batch group have a pair-aware twin (tcq_gemv_pair.hip)
+    bool plain = nbg == 1;  // pair mode: the plain TCQ kernels of one batch group have a pair-aware twin (tcq_gemv_pair.hip; any-KV: tcq_gemv_any.hip)
     for (int j = 0; j < njobs; j++) plain = plain && !mp.job[j].x_rot;
     plan_launch(mp, zeroed, grid, waves_of(nbg), plain);
     for (int j = 0; j < njobs; j++) {

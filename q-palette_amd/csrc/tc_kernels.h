@@ -760,7 +760,10 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     // launch — without early staging they have no spills and the q | k | v launch of a mixed-scheme model takes 7.1 instead of
     // 8.3 us (llama3.1-8b_figure1c 651 -> 707 tok/s, mem3p25 678 -> 722, one box: profiles/r03_ab_any_spills.txt).
     constexpr bool PAIRK = ROT == 3;  // plain kernel that also understands pair-mode jobs (sk == -1, TcParams)
-    constexpr bool kEarly = NBG == 1 && (ROT == 0 || ROT == 3) && NV * NT <= 4096 && !is_any_v<C1>;
+#ifndef QPAL_ANY_EARLY
+#define QPAL_ANY_EARLY 1  // round 4: with the early loads outside the compiler's bookkeeping (inline asm) and the first item as its own
+#endif                    // body, the any-KV kernels hold them without spilling (round 3: 16-28 spilled VGPRs, early staging off)
+    constexpr bool kEarly = NBG == 1 && (ROT == 0 || ROT == 3) && NV * NT <= 4096 && (QPAL_ANY_EARLY || !is_any_v<C1>) && !is_mix_v<C1>;
     constexpr int EV = NV < 4 ? NV : 4;  // image entries a thread holds across the argument fetch; the rest are built after it
     constexpr int XR = kEarlyXChunks;    // 16-byte chunks of x a thread holds likewise
     [[maybe_unused]] u32x4 exr[XR];
