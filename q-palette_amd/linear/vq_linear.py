@@ -1,5 +1,7 @@
 """VQ / non-uniform-SQ linears on the tensor-core-order packing and on the SIMT packing
 (reference: lib/linear/vq_linear.py:5-97, 99-208)."""
+import os
+
 import torch
 
 from .. import ops
@@ -59,8 +61,39 @@ class VQLinearPackTensorCore(_VQBase):
         return [f"decompress_gemm_{m}_{bs}_{k}_{self.lut_bits}_{self.vq_type}" for bs in range(1, self.max_fused_batch + 1)] + \
                [f"decompress_{self.lut_bits}_{self.vq_type}"]
 
+    # Few-row layers (k / v / kv projections: <= 64 supertile rows) occupy 32-64 of the 256 compute units in the tensor-core-order
+    # kernel, one workgroup per supertile row, and the wide codebooks make every step heavy: on MI355X the SIMT-order kernel runs
+    # the same layer in half the time (perf/latency/3_8b_latency_coeffs_mi355x.json: k_ldlq_1_8 13.5 vs 4.8 us; with the
+    # tensor-core kernel these were the 12 table entries an RTX 4090 beat).  For such layers the module keeps a SIMT-order copy of
+    # its codes, re-packed on the device at the first decode call (what VQLinearPackSIMT.gen_layer_from_info does at load time,
+    # lib/linear/vq_linear.py:175-188) — a few MB per layer — and its batch <= 8 forward runs the SIMT kernel (fp16 out, fp32
+    # accumulate).  `qweight` stays the reference's buffer: state dicts, get_weight() and the fused multi-job launches are unchanged.
+    SIMT_TWIN_MAX_ROWS = 2048
+
+    def _simt_twin(self):
+        tw = getattr(self, "_simt_qweight", None)
+        if tw is not None and tw.device == self.qweight.device:
+            return tw
+        if (self.out_features > self.SIMT_TWIN_MAX_ROWS or not self.qweight.is_cuda or os.environ.get("QPAL_SIMT_TWIN", "1") == "0"
+                or (self.vec_sz == 2 and self.lut_bits < 3) or torch.compiler.is_compiling() or torch.cuda.is_current_stream_capturing()):
+            return None
+        tw = ops.tc_to_simt(self.qweight, self.out_features, self.in_features, self.lut_bits, self.vec_sz)
+        object.__setattr__(self, "_simt_qweight", tw)  # (not a buffer: never part of the state dict)
+        ops.register_names(["sq_pack_gemm_simt"] if self.vec_sz == 1 else
+                           [f"vq_pack_gemm_simt_{bs}_{self.vec_sz}_{self.lut_bits}" for bs in range(1, 9)])
+        return tw
+
     def _gemv(self, x, bs):
         m, k = self.out_features, self.in_features
+        if bs <= 8:
+            tw = self._simt_twin()
+            if tw is not None:
+                x3 = x.reshape(bs, 1, k)
+                if x3.dtype != torch.float16:
+                    x3 = x3.half()
+                y = (op("sq_pack_gemm_simt")(x3, tw, self.lut, self.lut_bits) if self.vec_sz == 1
+                     else op(f"vq_pack_gemm_simt_{bs}_{self.vec_sz}_{self.lut_bits}")(x3, tw, self.lut))
+                return y.reshape(bs, m)
         return op(f"decompress_gemm_{m}_{bs}_{k}_{self.lut_bits}_{self.vq_type}")(self.qweight, x, self.lut)
 
     def get_weight(self):

@@ -203,7 +203,10 @@ def test_llama_shapes_modules(qp, oracle, qstr, k, m):
         x = torch.randn(n, k, generator=gen).half()
         y = layer(x.cuda().float())  # fp32 in -> fp32 out keeps the kernel's fp32 result
         assert y.dtype == torch.float32 and tuple(y.shape) == (n, m)
-        _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle)
+        # (few-row VQ / SQ layers run the SIMT-order kernel on a re-packed copy of their codes at batch <= 8: fp16 output)
+        simt_twin = isinstance(layer, qp.VQLinearPackTensorCore) and m <= layer.SIMT_TWIN_MAX_ROWS
+        assert simt_twin == (getattr(layer, "_simt_qweight", None) is not None)
+        _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle, fp16_out=simt_twin)
     # bs > max_fused_batch (64): the module's decode-to-fp16 + fp16 GEMM path — what the perplexity eval exercises
     # (eval_qdict.py:17-38 at bs = 8192; lib/linear/tcq_linear.py:75-84); tighter check: test_module_path_above_the_fused_batch
     x = torch.randn(80, k, generator=gen).half()
