@@ -136,9 +136,73 @@ struct AttnRopeParams {
     float scale;
 };
 
-// body: one workgroup of NW waves = one query head; `cap` = positions the score buffer holds (pos < cap)
+// What a thread of the one-head body reads from global memory that does NOT depend on the position: its element of inv_freq and of
+// the new q / k (or v) row, and its first round of cache rows for the score and the value loops (rows past `pos` are masked later;
+// any row below max_len is readable).  Round 4: requested at the top of the kernel, BEFORE *pos is waited for — the body was a
+// chain of five dependent round trips (arguments -> *pos -> inv_freq -> q / k -> cache rows), ~2 of its 5.6 us.
+template <int HD>
+struct AttnPre {
+    uint32_t inv, x1, x2;   // fp32 bit patterns
+    u32x4 k4[4];
+    u32x2 vraw[4];          // DPL = HD / 64 halves per lane: 2, 4 or 8 bytes (the low ones are used)
+};
+// (inline asm, in this order: the compiler neither sinks the loads below the wait for *pos nor reorders the cold cache rows in
+// front of the three small reads the rotary embedding waits for; attn_landed_* are the matching waits)
 template <int HD, int NW>
-__device__ __forceinline__ void attn_rope_head(const AttnRopeParams &p, float *sh, const int head, const long pos, const long cap) {
+__device__ __forceinline__ void attn_prefetch(const AttnRopeParams &p, const int head, AttnPre<HD> &pre) {
+    constexpr int HALF = HD / 2, LPR = HD / 8, RPW = 64 / LPR, DPL = HD / 64;
+    const int rep = p.nq / p.nkv, kh = head / rep;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint16_t *K = p.kcache + (long)kh * p.max_len * HD, *V = p.vcache + (long)kh * p.max_len * HD;
+    {
+        // unconditional loads from clamped addresses: threads [0, HALF) the q row, [HALF, 2 HALF) the k row, [2 HALF, 2 HALF + HD)
+        // the v row, the rest re-read element 0
+        const bool is_q = tid < HALF, is_k = !is_q && tid < 2 * HALF, is_v = tid >= 2 * HALF && tid < 2 * HALF + HD;
+        const float *src = is_q ? p.q + (long)head * HD : is_k ? p.k + (long)kh * HD : p.v + (long)kh * HD;
+        const int i = is_q ? tid : is_k ? tid - HALF : is_v ? tid - 2 * HALF : 0;
+        const float *a_inv = p.inv_freq + (i < HALF ? i : 0), *a1 = src + i, *a2 = src + ((is_q || is_k) ? i + HALF : i);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(pre.inv) : "v"(a_inv));
+        asm volatile("global_load_dword %0, %1, off" : "=v"(pre.x1) : "v"(a1));
+        asm volatile("global_load_dword %0, %1, off" : "=v"(pre.x2) : "v"(a2));
+    }
+    const int grp = lane / LPR, sl = lane % LPR;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const long t = (long)wave * RPW + (long)u * NW * RPW + grp;
+        const uint16_t *a = K + (t < p.max_len ? t : 0) * HD + 8 * sl;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre.k4[u]) : "v"(a));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const long t = wave + (long)u * NW;
+        const uint16_t *a = V + (t < p.max_len ? t : 0) * HD + DPL * lane;
+        if constexpr (DPL == 1) asm volatile("global_load_ushort %0, %1, off" : "=v"(pre.vraw[u].x) : "v"(a));
+        else if constexpr (DPL == 2) asm volatile("global_load_dword %0, %1, off" : "=v"(pre.vraw[u].x) : "v"(a));
+        else asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pre.vraw[u]) : "v"(a));
+    }
+}
+// the three small reads have landed (8 younger prefetch loads may be outstanding)
+template <int HD>
+__device__ __forceinline__ void attn_landed_small(AttnPre<HD> &pre) {
+    asm volatile("s_waitcnt vmcnt(8)" : "+v"(pre.inv), "+v"(pre.x1), "+v"(pre.x2)::"memory");
+}
+// the key rows have landed (the 4 value-row loads are younger; the cache-append stores issued since then only make this stricter)
+template <int HD>
+__device__ __forceinline__ void attn_landed_keys(AttnPre<HD> &pre) {
+    asm volatile("s_waitcnt vmcnt(4)" : "+v"(pre.k4[0]), "+v"(pre.k4[1]), "+v"(pre.k4[2]), "+v"(pre.k4[3])::"memory");
+}
+template <int HD>
+__device__ __forceinline__ void attn_landed_values(AttnPre<HD> &pre) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre.vraw[0]), "+v"(pre.vraw[1]), "+v"(pre.vraw[2]), "+v"(pre.vraw[3])::"memory");
+}
+
+// body: one workgroup of NW waves = one query head; `cap` = positions the score buffer holds (pos < cap)
+template <int HD, int NW, bool PRE = false>
+__device__ __forceinline__ void attn_rope_head(const AttnRopeParams &p, float *sh, const int head, const long pos, const long cap,
+                                               AttnPre<HD> *pre_p = nullptr, const bool ok = true) {
+    // ok == false (PRE form only: *pos was outside the cache; the caller passes pos = 0): the body runs — no early return stands
+    // between the prefetch and its uses, which is what lets the compiler issue the prefetch before it waits for *pos — and
+    // writes nothing
     constexpr int NT = 64 * NW, HALF = HD / 2;
     constexpr int LPR = HD / 8;        // lanes per cache row in the score loop
     constexpr int RPW = 64 / LPR;      // rows per wave instruction
@@ -151,29 +215,38 @@ __device__ __forceinline__ void attn_rope_head(const AttnRopeParams &p, float *s
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const gptr<const uint16_t> K = as_global(p.kcache) + (long)kh * p.max_len * HD, V = as_global(p.vcache) + (long)kh * p.max_len * HD;
 
+    if constexpr (PRE) attn_landed_small(*pre_p);
     // ---- new token: rope(q) -> LDS as fp16 pairs, rope(k), v -> LDS (+ cache, first head of the group)
     for (int idx = tid; idx < 2 * HALF + HD; idx += NT) {
         if (idx < 2 * HALF) {
             const bool is_k = idx >= HALF;
             const int i = is_k ? idx - HALF : idx;
             const float *src = is_k ? p.k + (long)kh * HD : p.q + (long)head * HD;
-            const float ang = (float)pos * p.inv_freq[i];
+            float inv_f, f1, f2;
+            if constexpr (PRE) {  // (NT >= 2 HD: one round, idx == tid)
+                inv_f = __builtin_bit_cast(float, pre_p->inv); f1 = __builtin_bit_cast(float, pre_p->x1); f2 = __builtin_bit_cast(float, pre_p->x2);
+            }
+            else { inv_f = p.inv_freq[i]; f1 = src[i]; f2 = src[i + HALF]; }
+            const float ang = (float)pos * inv_f;
             const _Float16 c = (_Float16)cosf(ang), s = (_Float16)sinf(ang);
-            const _Float16 x1 = (_Float16)src[i], x2 = (_Float16)src[i + HALF];
+            const _Float16 x1 = (_Float16)f1, x2 = (_Float16)f2;
             const _Float16 o1 = x1 * c + (-x2) * s, o2 = x2 * c + x1 * s;
             uint16_t *dst16 = reinterpret_cast<uint16_t *>(is_k ? knh : qh);
             dst16[i] = __builtin_bit_cast(uint16_t, o1);
             dst16[i + HALF] = __builtin_bit_cast(uint16_t, o2);
-            if (is_k && head % rep == 0) {
+            if (is_k && head % rep == 0 && ok) {
                 uint16_t *dst = p.kcache + ((long)kh * p.max_len + pos) * HD;
                 dst[i] = __builtin_bit_cast(uint16_t, o1);
                 dst[i + HALF] = __builtin_bit_cast(uint16_t, o2);
             }
         } else {
             const int d = idx - 2 * HALF;
-            const _Float16 hv = (_Float16)p.v[(long)kh * HD + d];
+            float fv;
+            if constexpr (PRE) fv = __builtin_bit_cast(float, pre_p->x1);
+            else fv = p.v[(long)kh * HD + d];
+            const _Float16 hv = (_Float16)fv;
             vn[d] = (float)hv;
-            if (head % rep == 0) p.vcache[((long)kh * p.max_len + pos) * HD + d] = __builtin_bit_cast(uint16_t, hv);
+            if (head % rep == 0 && ok) p.vcache[((long)kh * p.max_len + pos) * HD + d] = __builtin_bit_cast(uint16_t, hv);
         }
     }
     __syncthreads();
@@ -182,12 +255,22 @@ __device__ __forceinline__ void attn_rope_head(const AttnRopeParams &p, float *s
     const int grp = lane / LPR, sl = lane % LPR;  // row inside the wave instruction, 16-byte slice of the row
     const u32x4 qv = *reinterpret_cast<const u32x4 *>(qh + 4 * sl);
     float mx = -3.0e38f;
+    if constexpr (PRE) attn_landed_keys(*pre_p);
     for (long t0 = (long)wave * RPW; t0 < pos; t0 += (long)NW * RPW * 4) {
         u32x4 kv[4];
+        bool have = false;
+        if constexpr (PRE) have = t0 == (long)wave * RPW;  // the first round was requested at the top of the kernel
+        if (have) {
+            if constexpr (PRE) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const long t = t0 + (long)u * NW * RPW + grp;
-            kv[u] = *(gptr<const u32x4>)(K + (t < pos ? t : 0) * HD + 8 * sl);
+                for (int u = 0; u < 4; u++) kv[u] = pre_p->k4[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const long t = t0 + (long)u * NW * RPW + grp;
+                kv[u] = *(gptr<const u32x4>)(K + (t < pos ? t : 0) * HD + 8 * sl);
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -245,16 +328,32 @@ __device__ __forceinline__ void attn_rope_head(const AttnRopeParams &p, float *s
     float acc[DPL];
 #pragma unroll
     for (int e = 0; e < DPL; e++) acc[e] = 0.f;
+    if constexpr (PRE) attn_landed_values(*pre_p);
     for (long t0 = wave; t0 < pos; t0 += NW * 4) {
         uint16_t raw[4][DPL];
         float w4[4];
+        bool havev = false;
+        if constexpr (PRE) havev = t0 == wave;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const long t = t0 + (long)u * NW;
-            const gptr<const uint16_t> row = V + (t < pos ? t : 0) * HD + DPL * lane;
-            if constexpr (DPL == 1) raw[u][0] = row[0];
-            else if constexpr (DPL == 2) { const uint32_t r = *(gptr<const uint32_t>)row; raw[u][0] = (uint16_t)r; raw[u][1] = (uint16_t)(r >> 16); }
-            else { const u32x2 r = *(gptr<const u32x2>)row; raw[u][0] = (uint16_t)r.x; raw[u][1] = (uint16_t)(r.x >> 16); raw[u][2] = (uint16_t)r.y; raw[u][3] = (uint16_t)(r.y >> 16); }
+            if (havev) {
+                if constexpr (PRE) {
+                    const u32x2 r = pre_p->vraw[u];
+                    raw[u][0] = (uint16_t)r.x;
+                    if constexpr (DPL >= 2) raw[u][1] = (uint16_t)(r.x >> 16);
+                    if constexpr (DPL == 4) { raw[u][2] = (uint16_t)r.y; raw[u][3] = (uint16_t)(r.y >> 16); }
+                    if (!(t < pos)) {  // a prefetched row past the context: whatever the cache holds there (0 * NaN is NaN)
+#pragma unroll
+                        for (int e = 0; e < DPL; e++) raw[u][e] = 0;
+                    }
+                }
+            } else {
+                const gptr<const uint16_t> row = V + (t < pos ? t : 0) * HD + DPL * lane;
+                if constexpr (DPL == 1) raw[u][0] = row[0];
+                else if constexpr (DPL == 2) { const uint32_t r = *(gptr<const uint32_t>)row; raw[u][0] = (uint16_t)r; raw[u][1] = (uint16_t)(r >> 16); }
+                else { const u32x2 r = *(gptr<const u32x2>)row; raw[u][0] = (uint16_t)r.x; raw[u][1] = (uint16_t)(r.x >> 16); raw[u][2] = (uint16_t)r.y; raw[u][3] = (uint16_t)(r.y >> 16); }
+            }
             w4[u] = t < pos ? sc[t] : 0.f;
         }
 #pragma unroll
@@ -274,16 +373,20 @@ __device__ __forceinline__ void attn_rope_head(const AttnRopeParams &p, float *s
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; w++) v += po[w * HD + d];
-        p.out[(long)head * HD + d] = __builtin_bit_cast(uint16_t, (_Float16)(v / sum));
+        if (ok) p.out[(long)head * HD + d] = __builtin_bit_cast(uint16_t, (_Float16)(v / sum));
     }
 }
 
 template <int HD>
 __global__ __launch_bounds__(1024) void attn_rope_decode_kernel(const AttnRopeParams p) {
     extern __shared__ float sh[];
-    const long pos = *p.pos;
-    if (pos < 0 || pos >= p.max_len) return;  // position outside the cache: nothing is read or written
-    attn_rope_head<HD, 16>(p, sh, blockIdx.x, pos, p.max_len);
+    // *pos through the scalar cache (constant address space: an s_load; as an ordinary load behind the inline-asm prefetch it became a
+    // VECTOR load, and the wait for it — vmcnt(0) — waited for every prefetched cache row as well)
+    const long pos_raw = *(const __attribute__((address_space(4))) long *)p.pos;
+    AttnPre<HD> pre;
+    attn_prefetch<HD, 16>(p, blockIdx.x, pre);  // everything that does not depend on the position is requested before *pos is waited for
+    const bool ok = pos_raw >= 0 && pos_raw < p.max_len;  // position outside the cache: nothing is written
+    attn_rope_head<HD, 16, true>(p, sh, blockIdx.x, ok ? pos_raw : 0, p.max_len, &pre, ok);
 }
 
 // Split-context form of the above for long caches (flash-decoding shape).  One workgroup per query head streams the whole

@@ -487,67 +487,19 @@ __device__ __forceinline__ void gemv_step(const uint32_t *lut, uint32_t laneoff,
     });
 }
 
-// Weights of step `step` when it exists (step < s1); otherwise every lane reads the stream's first 16 + bytes — a prefetch slot that
-// costs an instruction and a wait-count slot but no bandwidth.  Always issued: a load under a branch makes the compiler's wait
-// counts conservative (it must assume the shorter queue), which silently turns a two-deep prefetch into a one-deep one.
-template <int NW>
-__device__ __forceinline__ void load_step_w_or_dummy(const StreamView &sv, int step, int s1, int lane, uint32_t (&w)[NW]) {
-    int sc = step * 4 + (lane >> 4);
-    sc = sc < sv.nsc ? sc : sv.nsc - 1;
-    const uint32_t off = (uint32_t)sc * (16u * NW) + (uint32_t)(lane & 15) * NW;
-    load_words_nt<NW>(sv.base + (step < s1 ? off : 0u), w);
-}
-
 // steps [s0, s1) of one stream; `w` already holds step s0 (loaded before the codebook image was built).
-// QPAL_PREFETCH_DEPTH == 1 (rounds 1-3): two register sets ping-pong (loop unrolled by 2), one step ahead.
-// QPAL_PREFETCH_DEPTH == 2 (round 4): three register sets, TWO steps ahead.  Why: the in-kernel stamps of round 4 have a wave's
-// step at 0.36-0.41 us inside the launches against 0.31 for the same step on register-resident words (bench.py `decode_rate`) —
-// with one step (256 KV bytes) in flight per wave a CU has <= 27 KB on its way, and at the ~1.5 us a load takes while the chip
-// streams 4-5 TB/s that is less than the four waves of a SIMD decode in the meantime (4 x 0.31 us): every step waited ~0.25 us.
-// (Round 3's ring experiments lost 10-19 %: they padded every wave's steps to whole rounds of three — up to 28 % more decode work
-// on the 7- and 8-step waves of gate | up — and issued the tail loads under branches.  Here nothing is padded, and steps past
-// the end request a dummy.)
-#ifndef QPAL_PREFETCH_DEPTH
-#define QPAL_PREFETCH_DEPTH 1
-#endif
+// Two register sets ping-pong (loop unrolled by 2) so the one-step-ahead prefetch costs no copies.
+// Deeper prefetch, measured and not kept.  Round 3: two or three steps in flight with every wave's steps padded to whole rounds of
+// three: 10-19 % slower (profiles/r03_ab_ring.txt).  Round 4 (profiles/r04_ab_prologue.txt (4), r04_ab_depth2_long_only.txt): three
+// register sets, TWO steps ahead, nothing padded, steps past the end requesting a 16-byte dummy so that no load sits under a
+// branch — every launch kind 0.4-0.7 us slower (124 instead of 91 VGPRs, 1.5 x the code, the compiler's wait in the first of
+// the three bodies still covers the newer step); restricted to chunks of >= 3 (>= 5) steps, i.e. gate | up and down only:
+// gate | up +-0, down +0.9 us (+0.1).  The stamps' 0.36 us per step inside gate | up against 0.31 on register-resident words
+// is therefore not load latency a deeper register prefetch recovers.
 template <class Codec, bool XLDS, int NBG>
 __device__ __forceinline__ void gemv_run(uint32_t (&w)[Codec::NW], const uint32_t *lut, uint32_t laneoff,
                                          const StreamView &sv, const uint16_t *xg, const uint16_t *xs, int k, int n,
                                          int zero_off, int s0, int s1, int lane, Acc<NBG> &acc) {
-#if QPAL_PREFETCH_DEPTH == 2
-    if constexpr (NBG == 1) {
-        if (s0 >= s1) return;
-        uint32_t wb[Codec::NW], wc[Codec::NW];
-        load_step_w_or_dummy<Codec::NW>(sv, s0 + 1, s1, lane, wb);
-        for (int s = s0;; s += 3) {
-            {
-                load_step_w_or_dummy<Codec::NW>(sv, s + 2, s1, lane, wc);
-                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's decode (hipcc sinks it otherwise)
-                u32x4 xb[NBG][2];
-                load_step_x<XLDS, NBG>(sv, xg, xs, k, n, zero_off, s, lane, xb);
-                gemv_step<Codec, NBG>(lut, laneoff, w, xb, acc);
-            }
-            if (s + 1 >= s1) break;
-            {
-                load_step_w_or_dummy<Codec::NW>(sv, s + 3, s1, lane, w);
-                __builtin_amdgcn_sched_barrier(0);
-                u32x4 xb[NBG][2];
-                load_step_x<XLDS, NBG>(sv, xg, xs, k, n, zero_off, s + 1, lane, xb);
-                gemv_step<Codec, NBG>(lut, laneoff, wb, xb, acc);
-            }
-            if (s + 2 >= s1) break;
-            {
-                load_step_w_or_dummy<Codec::NW>(sv, s + 4, s1, lane, wb);
-                __builtin_amdgcn_sched_barrier(0);
-                u32x4 xb[NBG][2];
-                load_step_x<XLDS, NBG>(sv, xg, xs, k, n, zero_off, s + 2, lane, xb);
-                gemv_step<Codec, NBG>(lut, laneoff, wc, xb, acc);
-            }
-            if (s + 3 >= s1) break;
-        }
-        return;
-    }
-#endif
     uint32_t wb[Codec::NW];
     for (int s = s0; s < s1; s += 2) {
         {

@@ -281,7 +281,9 @@ def test_multi_job_launch_equals_single_launches(qp):
             ys = qp.multi_gemv(layers, x)
             for layer, y in zip(layers, ys):
                 ref = layer._gemv(x, n)
-                assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+                # (a few-row VQ / SQ layer answers a single launch from its SIMT-order twin: fp16 output)
+                rtol = 1e-4 if ref.dtype == torch.float32 else 2.0 ** -10
+                assert torch.allclose(y, ref.float(), rtol=rtol, atol=rtol * float(ref.abs().max()))
 
 
 def test_early_and_late_staging_agree(qp):
