@@ -203,20 +203,28 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
             else load_step_w<C1::NW>(sv1, st.s, lane, reinterpret_cast<uint32_t(&)[C1::NW]>(dst));
         };
         // chunk id -> (batch row b = id >> 4, 16-byte piece q = id & 15 of the step's 128 columns)
+        // (unconditional loads from clamped addresses — a dead chunk re-reads x[0..7] and is zeroed when it is stored: a load under a
+        // condition makes the compiler's wait counts conservative, and the wait for a tile then waits for the weights behind it)
+        auto x_live = [&](int g, int r) {
+            const GemmStep st = gemm_where(p, g);
+            const int id = tid + r * NT;
+            return id < NCH && (id >> 4) < p.n && st.col_base + 8 * (id & 15) < st.col_end;
+        };
         auto load_x = [&](int g) {
             const GemmStep st = gemm_where(p, g);
 #pragma unroll
             for (int r = 0; r < CPT; r++) {
                 const int id = tid + r * NT;
                 const int b = id >> 4, col = st.col_base + 8 * (id & 15);
-                xr[r] = u32x4{0u, 0u, 0u, 0u};
-                if (id < NCH && b < p.n && col < st.col_end) xr[r] = *reinterpret_cast<const u32x4 *>(p.x + (long)b * p.k + col);
+                const bool ok = id < NCH && b < p.n && col < st.col_end;
+                xr[r] = *reinterpret_cast<const u32x4 *>(p.x + (ok ? (long)b * p.k + col : 0l));
             }
         };
-        auto store_x = [&](unsigned char *buf) {
+        auto store_x = [&](unsigned char *buf, int g) {
 #pragma unroll
             for (int r = 0; r < CPT; r++) {
                 const int id = tid + r * NT;
+                if (!x_live(g, r)) xr[r] = u32x4{0u, 0u, 0u, 0u};
                 if (id < NCH) {
                     const int b = id >> 4, q = id & 15;
                     // piece q = (supertile col sc = q >> 2, ksub = (q >> 1) & 1, jh = q & 1): halves 0..3 belong to column half u = 0, 4..7 to u = 1
@@ -245,11 +253,11 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
             cur_tab = p.tab;
         }
         if constexpr (AHEAD == 2) {
-            store_x(xt + XBUF);
+            store_x(xt + XBUF, g0 + 1 < g1 ? g0 + 1 : g0);
 #pragma unroll
             for (int r = 0; r < CPT; r++) xr[r] = xr1[r];
         }
-        store_x(xt);
+        store_x(xt, g0);
         Acc<NBG> acc;
         static_for<0, NBG>([&](auto bc) {
             static_for<0, 4>([&](auto ac) { acc.v[decltype(bc)::value][decltype(ac)::value] = float4_t{0.f, 0.f, 0.f, 0.f}; });
@@ -260,19 +268,29 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
         // already belongs to the next stream (or re-requests the last step)
         auto run = [&](auto codec_c, int ga, int gb) {
             using CC = typename decltype(codec_c)::type;
+            constexpr bool SECOND = TWO && std::is_same_v<CC, CB> && !std::is_same_v<C1, CB>;
             for (int g = ga; g < gb; g++) {
-                const int gn = g + 1 < g1 ? g + 1 : g;
+                // Round 4: the tile FIRST (it is stored to LDS at the end of this step; the weights are next step's), and the weight
+                // prefetch without a branch — the next step of THIS stream, the last one re-requesting itself; the first step of
+                // the other stream is requested by the caller at the switch.  With the codec branch of load_w and the predicated
+                // tile loads the compiler waited `vmcnt(0)` before the tile's LDS stores: every step waited for the NEXT step's
+                // weights, a full HBM round trip where the step is shorter than that (batches 4..32).
+                const int xg = g + AHEAD < g1 ? g + AHEAD : g1 - 1;
+                if constexpr (!(QPAL_GEMM_KO & 4)) load_x(xg);
                 if constexpr (QPAL_GEMM_KO & 32) {
 #pragma unroll
                     for (int i = 0; i < NWMAX; i++) wnext[i] = wcur[i] + 1;
-                } else load_w(gn, wnext);
-                if constexpr (!(QPAL_GEMM_KO & 4)) load_x(g + AHEAD < g1 ? g + AHEAD : g1 - 1);
+                } else {
+                    const int gn = g + 1 < gb ? g + 1 : g;
+                    if constexpr (SECOND) load_step_w<CC::NW>(sv2, gn - p.st1, lane, reinterpret_cast<uint32_t(&)[CC::NW]>(wnext));
+                    else load_step_w<CC::NW>(sv1, gn, lane, reinterpret_cast<uint32_t(&)[CC::NW]>(wnext));
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 const int i = g - g0;
                 if (live)  // (wave-uniform: a row past the end of the layer only keeps the staging and the barriers company)
                     gemm_step<CC, NBG>(lut, laneoff, reinterpret_cast<uint32_t(&)[CC::NW]>(wcur), xt + (i & (NSLOT - 1)) * XBUF, lane, acc);
                 // slot of step i + AHEAD: last read AHEAD steps ago, i.e. before the latest barrier
-                if constexpr (!(QPAL_GEMM_KO & 4)) store_x(xt + ((i + AHEAD) & (NSLOT - 1)) * XBUF);
+                if constexpr (!(QPAL_GEMM_KO & 4)) store_x(xt + ((i + AHEAD) & (NSLOT - 1)) * XBUF, xg);
                 if constexpr (!(QPAL_GEMM_KO & 8)) {
                     if (AHEAD == 1 || (i & 1)) __syncthreads();
                 }
@@ -284,7 +302,10 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
             const int mid = g1 < p.st1 ? g1 : (g0 > p.st1 ? g0 : p.st1);
             if (g0 < mid) run(std::type_identity<C1>{}, g0, mid);
             if constexpr (TWO) {
-                if (mid < g1) run(std::type_identity<CB>{}, mid, g1);
+                if (mid < g1) {
+                    if (g0 < mid) load_w(mid, wcur);  // the switch to stream 2 inside an item: its first step, requested here (one exposed round trip)
+                    run(std::type_identity<CB>{}, mid, g1);
+                }
             }
         }
 
