@@ -1170,7 +1170,13 @@ def load_traffic(workload):
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload)
+            data = json.load(f)
+        # the committed figure belongs to ONE version of the kernels: another library (QPAL_VERSION bumped with the kernels) -> null,
+        # not a stale number
+        import qpalette_amd as qp
+        if data.get("_qpal_version") is not None and data["_qpal_version"] != qp._native.lib().qpal_version():
+            return None
+        return data.get(workload)
     except (OSError, ValueError):
         return None
 
