@@ -7,7 +7,7 @@ int launch_lut_tc_gemv_pair(const TcMultiParams &p, int bits, int vec, int grid,
     const TcEarly e = early_args(p);
 #define QPAL_LUT(B_, V_)                                                                                       \
     if (bits == B_ && vec == V_) {                                                                             \
-        hipLaunchKernelGGL((tc_gemv_kernel<LutCodec<B_, V_>, void, 1, 3>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.su, e.rw, p); \
+        hipLaunchKernelGGL((tc_gemv_kernel<LutCodec<B_, V_>, void, 1, 3>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, p); \
         return (int)hipGetLastError();                                                                         \
     }
 #include "lut_table.inc"

@@ -9,7 +9,7 @@ int launch_lut_tc_gemv_rot28(const TcMultiParams &p, int bits, int vec, int grid
 #define QPAL_LUT(B_, V_)                                                                                           \
     if (bits == B_ && vec == V_) {                                                                                 \
         if constexpr (LutCodec<B_, V_>::LDS_DWORDS * 4 >= kP28 * kTbRow) {                                         \
-            hipLaunchKernelGGL((tc_gemv_kernel<LutCodec<B_, V_>, void, 1, 2>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.su, e.rw, p); \
+            hipLaunchKernelGGL((tc_gemv_kernel<LutCodec<B_, V_>, void, 1, 2>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, p); \
             return (int)hipGetLastError();                                                                         \
         } else {                                                                                                   \
             return QPAL_E_SHAPE;                                                                                   \

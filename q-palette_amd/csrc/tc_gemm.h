@@ -35,7 +35,7 @@ constexpr int kGemmXGroup = 16 * kGemmXRow;  // one batch group (8 rows x 2 colu
 #define QPAL_GEMM_PIPE 1
 #endif
 // Timing experiments only (results invalid): QPAL_GEMM_KO bit 1: no MFMAs (operands xor-folded), 2: no B-fragment reads, 4: no x
-// staging inside the loop, 8: no per-step barrier, 32: no weight loads inside the loop, 64: no output stores / atomics, 128: no codebook image build; -DQPAL_KO_GATHER: no codebook gathers.
+// staging inside the loop, 8: no per-step barrier, 32: no weight loads inside the loop, 64: no output stores / atomics, 128: no codebook image build, 256: no steps at all (what a launch costs before and after them); -DQPAL_KO_GATHER: no codebook gathers.
 #ifndef QPAL_GEMM_SLOTS
 #define QPAL_GEMM_SLOTS 4
 #endif
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
                 for (int i = 0; i < NWMAX; i++) wcur[i] = wnext[i];
             }
         };
-        {
+        if constexpr (!(QPAL_GEMM_KO & 256)) {
             const int mid = g1 < p.st1 ? g1 : (g0 > p.st1 ? g0 : p.st1);
             if (g0 < mid) run(std::type_identity<C1>{}, g0, mid);
             if constexpr (TWO) {

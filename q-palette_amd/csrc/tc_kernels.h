@@ -613,6 +613,9 @@ struct TcEarly {
     const uint16_t *su;  // rotating launches: sign vector (or null), RMSNorm weight (or null; the 14336-wide rotation: its hadK factor)
     const uint16_t *rw;
     float pre, post;     // the 14336-wide rotation: x_pre, x_post
+    int ie;              // != 0: item_end[0..2] of the launch's job table, 10 bits each (0x3ff: no such boundary), bit 30 set — a workgroup
+                         // knows the job of its FIRST item before the kernel-argument block has arrived, and requests THAT job's
+                         // parameters in the first scalar-load round trip (launches of <= 4 jobs; 0: it scans the table as before)
 };
 
 // host: the launch qualifies when x is staged in LDS and every job has the same x, codebook and batch
@@ -632,6 +635,14 @@ inline TcEarly early_args(const TcMultiParams &mp) {
             b.x_rms_w != a.x_rms_w || b.x_src_f32 != a.x_src_f32 || (b.x_rms_eps > 0.f) != (a.x_rms_eps > 0.f) || b.x_hadk != a.x_hadk ||
             b.x_pre != a.x_pre || b.x_post != a.x_post)
             e.on = 0;
+    }
+    e.ie = 0;
+    if (mp.njobs >= 2 && mp.njobs <= 4) {  // (one job: nothing to find out)
+        e.ie = 1 << 30;
+        for (int j = 0; j < 3; j++) {
+            const int end = j < mp.njobs - 1 ? mp.item_end[j] : 0x3ff;
+            e.ie |= (end < 0x3ff ? end : 0x3ff) << (10 * j);
+        }
     }
     return e;
 }
@@ -684,7 +695,7 @@ __device__ __forceinline__ void rot_stage1_regs(const u32x4 (&rq)[2][4], bool f3
 // ROT: 0 plain; 1: can rotate x while staging it (k = 2048 / 4096, wht64.h); 2: the 14336-wide rotation of rot_k28.h (its own
 // instantiation: its registers would make the other rotating launches spill); 3: plain + pair mode (TcParams: sk == -1)
 template <class C1, class C2, int NBG, int ROT = 0>
-__global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const void *etab, int en, int ek, int eon,
+__global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const void *etab, int en, int ek, int eon, int eie,
                                                        const uint16_t *esu, const uint16_t *erw, const TcMultiParams mp) {
     constexpr bool TWO = !std::is_void_v<C2>;
     using CB = std::conditional_t<TWO, C2, C1>;
@@ -696,13 +707,16 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t laneoff = (uint32_t)(lane & (C1::C - 1)) << 2;
+    // (measured and not kept, round 4: `s_setprio` tiers — one wave of every SIMD ahead of the next through the scalar prologue, so that a
+    // SIMD's first weights are requested after a quarter of it: -0.5 % tokens/s, profiles/r04_ab_prologue2.txt — the staging barrier
+    // waits for the slowest wave either way)
 #ifdef QPAL_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();  // the wave's first instruction (slot 2 of an early-staging launch)
 #endif
 
     const void *cur_tab = nullptr;      // codebook whose image is in LDS
     const uint16_t *cur_x = nullptr;    // activations staged in LDS
-    int cur_j = 0;
+    int cur_j = 0;  // (set to the first item's job below)
     // early staging, part 1: request x and the codebook entries from the preloaded arguments (held in registers until
     // the first weight loads have been issued)
     constexpr int NV = (C1::CHUNKS + NT - 1) / NT;
@@ -820,7 +834,24 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     int ie[kMaxJobs];
 #pragma unroll
     for (int i = 0; i < kMaxJobs; i++) ie[i] = mp.item_end[i];
-    TcParams p = mp.job[0];
+    // Which job does this workgroup's FIRST item belong to?  From the preloaded `eie` (early_args), i.e. before any kernel argument
+    // has arrived: the first round trip then fetches THAT job.  (Round 4: workgroups of jobs 1.. — a third of a q | k | v launch,
+    // half of a gate | up launch, and the launch ends with its slowest workgroup — scanned the item table after the first round
+    // trip and fetched their job in a second, dependent one: ~40 more scalar instructions and a memory round trip in front of their
+    // first weight loads.)
+    int jf = 0, ibf = 0;
+    if (eie != 0) {
+        const int b = (int)blockIdx.x, e0 = eie & 0x3ff, e1 = (eie >> 10) & 0x3ff, e2 = (eie >> 20) & 0x3ff;
+        if (b >= e0) {  // (nested: a workgroup of job 0 — most of them — leaves after one comparison)
+            jf = 1, ibf = e0;
+            if (b >= e1) {
+                jf = 2, ibf = e1;
+                if (b >= e2) jf = 3, ibf = e2;
+            }
+        }
+    }
+    TcParams p = mp.job[jf];
+    cur_j = jf;
     const int total_items = ie[kMaxJobs - 1];
     // Pin job 0's loads next to the item table's: left alone, the compiler requests job 0 only inside the loop, after
     // it has waited for the item table — two kernel-argument round trips on the critical path instead of one.
@@ -849,7 +880,10 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         // same scalar code get an issue slot every ~16 cycles each, and ~200 instructions stood between a wave's entry and its
         // first weight load: ~1 us of a 5-6 us launch)
         int j = 0, item_begin = 0;
-        if (gitem >= ie[0]) {
+        if (FIRST && eie != 0) {
+            j = jf;
+            item_begin = ibf;
+        } else if (gitem >= ie[0]) {
 #pragma unroll
             for (int i = 0; i < kMaxJobs - 1; i++) {
                 if (gitem >= ie[i]) {
@@ -907,13 +941,6 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         };
         const int sr = row_of(rloc);
         const bool live = sr < p.nrows;
-        // per-row output scale of the epilogue: requested now, consumed after the steps (a load issued there
-        // would put a whole memory round trip at the end of the kernel)
-        uint32_t wraw;
-        asm volatile("" : "=v"(wraw));  // "no value yet": a constant here would be merged with the load at the join
-                                        // below, and the merge waits for the load on the spot
-        if (p.wscale && tid < (32 << log2_rpw) && row_of(tid >> 5) < p.nrows)
-            wraw = p.wscale[row_of(tid >> 5) * 32 + (tid & 31)];
         // (measured and not kept: chunk wr * sk + ks for single-stream split-K rows, so that the `rem` longer chunks alternate
         // between the workgroups of a row — Llama-8B down_proj in tcq_6: 14 / 14 instead of 16 / 12 steps per SIMD — moved
         // nothing: tcq_6 +0.6 %, ldlq_1_4 -0.7 %, 70B +-0 (profiles/r03_ab_interleave_rem.txt).  That launch streams 23.9 MB in a
@@ -1202,6 +1229,15 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                 acc.v[decltype(bc)::value][decltype(ac)::value] = float4_t{0.f, 0.f, 0.f, 0.f};
             });
         });
+        // per-row output scale of the epilogue: requested HERE — behind the first weights and the staging (round 4: its ~25
+        // instructions stood in front of the first weight loads of every wave, and the path to those is bound by instruction issue) —
+        // and consumed after the steps (a load issued there
+        // would put a whole memory round trip at the end of the kernel)
+        uint32_t wraw;
+        asm volatile("" : "=v"(wraw));  // "no value yet": a constant here would be merged with the load at the join
+                                        // below, and the merge waits for the load on the spot
+        if (p.wscale && tid < (32 << log2_rpw) && row_of(tid >> 5) < p.nrows)
+            wraw = p.wscale[row_of(tid >> 5) * 32 + (tid & 31)];
         if constexpr (ANY) {
             if constexpr (is_mix_v<C1>) {
                 if (lut_job)

@@ -32,7 +32,7 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
         if (slot >= 0 && grid <= 256) {
             TcMultiParams mq = mp;
             mq.job[0].dbg = reinterpret_cast<unsigned long long *>(strtoull(sb, nullptr, 0)) + (size_t)slot * 256 * 16 * 8;
-            hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(64 * gemv_waves<NBG>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.su, e.rw, mq);
+            hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(64 * gemv_waves<NBG>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, mq);
             return (int)hipGetLastError();
         }
     }
@@ -49,7 +49,7 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
         hipMalloc(&d, nb);
         hipMemset(d, 0, nb);
         q.dbg = d;
-        for (int rep = 0; rep < 3; rep++) { TcMultiParams mq = mp; mq.job[0] = q; hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.su, e.rw, mq); }
+        for (int rep = 0; rep < 3; rep++) { TcMultiParams mq = mp; mq.job[0] = q; hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, mq); }
         hipDeviceSynchronize();
         unsigned long long *h = (unsigned long long *)malloc(nb);
         hipMemcpy(h, d, nb, hipMemcpyDeviceToHost);
@@ -91,7 +91,7 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
         hipFree(d);
     }
 #endif
-    hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(64 * gemv_waves<NBG>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.su, e.rw, mp);
+    hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(64 * gemv_waves<NBG>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, mp);
     return (int)hipGetLastError();
 }
 

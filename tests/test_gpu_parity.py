@@ -353,7 +353,10 @@ def test_ragged_shapes(qp, oracle, m, k):
         for n in (1, 2, 8):
             x = torch.randn(n, k, generator=gen).half()
             y = layer._gemv(x.cuda(), n)
-            _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle)
+            # (a few-row VQ / SQ layer in tensor-core packing answers batch <= 8 from its SIMT-order twin: fp16 output)
+            twin = isinstance(layer, qp.VQLinearPackTensorCore) and getattr(layer, "_simt_qweight", None) is not None
+            assert y.dtype == (torch.float16 if twin else torch.float32)
+            _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle, fp16_out=twin)
 
 
 def test_unsupported_shapes_raise(qp):
@@ -484,8 +487,10 @@ def test_tcomb_and_tcq_projections_share_one_launch(qp, oracle):
         outs = [torch.zeros(1, m, device="cuda") for m in ms]
         ys = qp.multi_gemv(mods, x, outs=outs, outs_zeroed=True, wscales=wsc, oscale=0.25)
         for (mod, _, _), y, w in zip(layers, ys, wsc):
-            ref = mod._gemv(x, 1) * w.float() * 0.25
-            assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+            r0 = mod._gemv(x, 1)
+            rt = 2e-3 if r0.dtype == torch.float16 else 1e-4   # (fp16: the layer answered from its SIMT-order twin)
+            ref = r0.float() * w.float() * 0.25
+            assert torch.allclose(y, ref, rtol=rt, atol=rt * float(ref.abs().max()))
     info = qp.mem_op.dummy_linear_info(k, 256, "tcomb_8_9_0.5_none_0.9", seed=1, codebook_seed=3)
     far = qp.make_linear_from_info("tcomb_8_9_0.5_none_0.9", info).cuda()
     assert sorted(len(g) for g in qp.linear.launch_groups([mods[0], far], mixed_kv=True)) == [1, 1]
@@ -517,7 +522,9 @@ def test_tcq_and_vq_sq_projections_share_one_launch(qp, oracle, monkeypatch):
             ys = qp.multi_gemv(mods, x)
             for (mod, qstr, info), y, m in zip(layers, ys, ms):
                 ref = mod._gemv(x, n)
-                assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max())), (qstrs, qstr, n)
+                # (a few-row VQ / SQ layer answers a single launch from its SIMT-order twin: fp16 output)
+                rt = 2e-3 if ref.dtype == torch.float16 else 1e-4
+                assert torch.allclose(y, ref.float(), rtol=rt, atol=rt * float(ref.abs().max())), (qstrs, qstr, n)
                 if n == 4:
                     _check_gemv(y.cpu().numpy(), _oracle_weight(oracle, qstr, info, m, k), x.half().cpu().numpy(), oracle)
         x = torch.randn(1, k, generator=torch.Generator().manual_seed(9)).cuda()
@@ -527,8 +534,10 @@ def test_tcq_and_vq_sq_projections_share_one_launch(qp, oracle, monkeypatch):
         ys = qp.multi_gemv(mods, x, outs=list(buf.split(list(ms), dim=1)), outs_zeroed=True, wscales=wsc, oscale=0.25, prezero=spare)
         assert float(spare.abs().max()) == 0.0
         for (mod, _, _), y, w in zip(layers, ys, wsc):
-            ref = mod._gemv(x, 1) * w.float() * 0.25
-            assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+            r0 = mod._gemv(x, 1)
+            rt = 2e-3 if r0.dtype == torch.float16 else 1e-4   # (fp16: the layer answered from its SIMT-order twin)
+            ref = r0.float() * w.float() * 0.25
+            assert torch.allclose(y, ref, rtol=rt, atol=rt * float(ref.abs().max()))
 
 
 class _RefStyleTCQ(torch.nn.Module):
