@@ -58,8 +58,17 @@ __global__ __launch_bounds__(1024) void stream(const u32x4 *w, long n, uint32_t 
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[0] = 1;
 }
 
+// what a launch could do for its successor in its tail: workgroup b touches the 28 KB workgroup b of the NEXT launch reads first
+// (the same workgroup index lands on the same XCD, i.e. behind the same L2) — mode 1: plain loads, 2: only every 8th workgroup
+// does it for a different workgroup (b + 1: another XCD's L2)
+__global__ __launch_bounds__(1024) void warm(const u32x4 *w, long wstride, int mode, uint32_t *sink) {
+    const int b = mode == 2 ? (blockIdx.x + 1) % gridDim.x : blockIdx.x;
+    const u32x4 v = w[(long)b * wstride + threadIdx.x * 2];
+    if ((v.x ^ v.y ^ v.z ^ v.w) == 0x9e3779b9u) sink[0] = 1;
+}
+
 template <int MODE>
-void run(const char *what, int tail, int stream_mb, u32x4 *x, uint32_t *tab, u32x4 *w, float *out, u32x4 *zero, unsigned long long *st) {
+void run(const char *what, int tail, int stream_mb, u32x4 *x, uint32_t *tab, u32x4 *w, float *out, u32x4 *zero, unsigned long long *st, int warm_mode = 0) {
     Big b{};
     hipStream_t s; (void)hipStreamCreate(&s);
     hipGraph_t g; hipGraphExec_t ge;
@@ -68,6 +77,7 @@ void run(const char *what, int tail, int stream_mb, u32x4 *x, uint32_t *tab, u32
     (void)hipStreamBeginCapture(s, hipStreamCaptureModeGlobal);
     for (int i = 0; i < N; i++) {
         if (stream_mb) hipLaunchKernelGGL(stream, dim3(256), dim3(1024), 0, s, w + (long)(i % 16) * (64 << 16), (long)stream_mb << 16, (uint32_t *)st);
+        if (warm_mode) hipLaunchKernelGGL(warm, dim3(256), dim3(1024), 0, s, w + (long)(i % 16) * (64 << 16) + (48 << 16), wstride * 16, warm_mode, (uint32_t *)st);
         hipLaunchKernelGGL((probe<MODE>), dim3(256), dim3(1024), 0, s, x, tab + (i % 4) * 512, w + (long)(i % 16) * (64 << 16) + (48 << 16), out, zero, tail, st,
                            wstride * 16, b);
     }
@@ -118,5 +128,11 @@ int main() {
         run<15>("all four (a GEMV prologue)", 0, mb, x, tab, w, out, zero, st);
         run<15>("all four (a GEMV prologue)", 3, mb, x, tab, w, out, zero, st);
     }
+    // does a line the PREVIOUS kernel touched from the same workgroup index (same XCD) come back faster?
+    run<4>("own 1.75 KB, touched by the launch before (same WG)", 0, 0, x, tab, w, out, zero, st, 1);
+    run<4>("own 1.75 KB, touched by the launch before (WG + 1)", 0, 0, x, tab, w, out, zero, st, 2);
+    run<4>("own 1.75 KB, 8 MB streamed, then touched (same WG)", 0, 8, x, tab, w, out, zero, st, 1);
+    run<15>("all four, touched by the launch before (same WG)", 0, 0, x, tab, w, out, zero, st, 1);
+    run<15>("all four, 8 MB streamed, then touched (same WG)", 0, 8, x, tab, w, out, zero, st, 1);
     return 0;
 }
