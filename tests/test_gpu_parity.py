@@ -286,6 +286,25 @@ def test_multi_job_launch_equals_single_launches(qp):
                 assert torch.allclose(y, ref.float(), rtol=rtol, atol=rtol * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("njobs", [2, 3, 4, 5, 8])
+def test_multi_job_launch_job_counts(qp, oracle, njobs):
+    """Launches of 2..8 jobs against the oracle: up to 4 jobs a workgroup knows the job of its first item from a preloaded
+    packed item table (tc_kernels.h `eie`), beyond that it scans the table in the kernel-argument block; unequal row counts put
+    the job boundaries at odd workgroup indices, and 8 x 1536 rows are more items than one round of workgroups."""
+    k = 4096
+    qstr = "tcq_6_none_0.9"
+    ms = ([1536] * 8 if njobs == 8 else [96, 2048, 32, 1024, 544][:njobs])
+    infos = [qp.mem_op.dummy_linear_info(k, m, qstr, seed=50 + i, codebook_seed=2) for i, m in enumerate(ms)]
+    layers = [qp.make_linear_from_info(qstr, info).cuda() for info in infos]
+    qp.share_codebooks(layers)
+    assert [len(g) for g in qp.linear.launch_groups(layers)] == [njobs]
+    for n in (1, 5):
+        x = torch.randn(n, k, generator=torch.Generator().manual_seed(njobs * 10 + n)).half()
+        ys = qp.multi_gemv(layers, x.cuda())
+        for info, y, m in zip(infos, ys, ms):
+            _check_gemv(y.cpu().numpy(), _oracle_weight(oracle, qstr, info, m, k), x.numpy(), oracle)
+
+
 def test_early_and_late_staging_agree(qp):
     """When all jobs of a launch share x and the codebook tensor, the kernel stages them from PRELOADED kernel arguments
     (before its argument block has arrived); with distinct codebook tensors of equal content it stages them the ordinary
