@@ -28,6 +28,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+TP_ABANDONED_RC = 75  # (EX_TEMPFAIL) --strict-exit: the multi-GPU leg was abandoned; the headline line was still printed
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
 WORKLOADS = {
@@ -91,6 +92,9 @@ def parse_args():
     ap.add_argument("--no-fuse-rotation", action="store_true",
                     help="--incoherent: always rotate in a launch of its own (default: inside the GEMV where k allows)")
     ap.add_argument("--layers", type=int, default=0, help="override the number of layers (0 = model's)")
+    ap.add_argument("--strict-exit", action="store_true",
+                    help=f"exit with code {TP_ABANDONED_RC} (instead of 0) when the tp_70b leg of an N > 1 run was abandoned or a rank died in "
+                         "it; the headline line is printed either way and carries \"tp_70b_abandoned\": true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo to rehearse ranks on one GPU")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: put every rank on this GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -146,8 +150,12 @@ def spawn_ranks(n):
             with open(park) as f:
                 out = json.load(f)
             out["tp_70b"] = {"error": f"a rank died inside the leg (exit code {rc}); the headline above was measured before it"}
+            out["tp_70b_abandoned"] = True
             print(json.dumps(out), flush=True)
-            rc = 0
+            print(f"[bench] a rank died inside the tp_70b leg (exit code {rc}); the headline line above was measured before it",
+                  file=sys.stderr, flush=True)
+            # the measured headline is reported with exit code 0 unless the caller asked for a failing code (--strict-exit)
+            rc = TP_ABANDONED_RC if "--strict-exit" in sys.argv else 0
         finally:
             os.remove(park)
     return rc
@@ -996,10 +1004,13 @@ def main():
                 printed[0] = True
                 out["tp_70b"] = {"error": f"abandoned after {args.tp_timeout} s (a rank failed or a collective did not complete); "
                                           "the headline above was measured before this leg"}
+                out["tp_70b_abandoned"] = True   # (top level: a run record can flag it without parsing the leg)
                 print(json.dumps(out), flush=True)
+                print(f"[bench] tp_70b leg ABANDONED after {args.tp_timeout} s; exit code {TP_ABANDONED_RC if args.strict_exit else 0}"
+                      f" (--strict-exit: {TP_ABANDONED_RC})", file=sys.stderr, flush=True)
                 if os.environ.get("QPAL_BENCH_HEADLINE_FILE") and os.path.exists(os.environ["QPAL_BENCH_HEADLINE_FILE"]):
                     os.remove(os.environ["QPAL_BENCH_HEADLINE_FILE"])
-            os._exit(0)
+            os._exit(TP_ABANDONED_RC if args.strict_exit else 0)
 
         park = os.environ.get("QPAL_BENCH_HEADLINE_FILE") if rank == 0 else None
         if park:
@@ -1129,38 +1140,42 @@ def tp_leg(qp, torch, dist, args, rank, world, device):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t[0]) / nsteps
 
-    for nb in (1, 16):
-        xs = {}
-        for groups in layers:
-            for mod, k, _ in (u for grp in groups for u in grp):
-                if k not in xs:
-                    xs[k] = torch.randn(nb, k, device=device).half()
-        abytes = algorithmic_bytes(qp, layers, nb)  # per rank
-        fig = {}
-        if peer is not None and res["peer_gather"].get("validated_against_collective"):
-            token, _ = make_token(qp, torch, layers, xs, nb, device, launch="multi", gather=peer)
-            t = timed(token, True)
-            torch.cuda.synchronize()
-            log(f"batch {nb}: peer gather in graph {t * 1e3:.2f} ms per step")
-            if all_ranks_ok(peer.error() == 0):
-                fig["peer_gather_in_graph"] = {"tokens_per_s": nb / t, "ms_per_step": t * 1e3}
-            else:
-                fig["peer_gather_in_graph"] = {"error": "a peer gather gave up waiting for a flag"}
-                res["peer_gather"]["validated_against_collective"] = False
-        coll = qp.shard.make_gatherer(world, device)
-        token, _ = make_token(qp, torch, layers, xs, nb, device, launch="multi", gather=coll)
-        t = timed(token, False)
-        log(f"batch {nb}: collective between eager launches {t * 1e3:.2f} ms per step")
-        fig["collective_eager"] = {"tokens_per_s": nb / t, "ms_per_step": t * 1e3}
-        valid = [v for v in fig.values() if "tokens_per_s" in v]
-        best = max(valid, key=lambda v: v["tokens_per_s"])
-        fig["value"] = best["tokens_per_s"]
-        fig["unit"] = "tokens/s"
-        fig["ms_per_step"] = best["ms_per_step"]
-        fig["roofline_frac_per_gpu"] = abytes / (best["ms_per_step"] / 1e3) / 1e9 / HBM_PEAK_GBS
-        res[f"bs{nb}"] = fig
-    if peer is not None:
-        peer.close()
+    try:  # (the peers' mapped allocations are released also when a leg raises)
+        for nb in (1, 16):
+            xs = {}
+            for groups in layers:
+                for mod, k, _ in (u for grp in groups for u in grp):
+                    if k not in xs:
+                        xs[k] = torch.randn(nb, k, device=device).half()
+            abytes = algorithmic_bytes(qp, layers, nb)  # per rank
+            fig = {}
+            if peer is not None and res["peer_gather"].get("validated_against_collective"):
+                token, _ = make_token(qp, torch, layers, xs, nb, device, launch="multi", gather=peer)
+                token()
+                peer.finish_token()  # (>= 2 call sites per token: checked on the token that is about to be captured and replayed)
+                t = timed(token, True)
+                torch.cuda.synchronize()
+                log(f"batch {nb}: peer gather in graph {t * 1e3:.2f} ms per step")
+                if all_ranks_ok(peer.error() == 0):
+                    fig["peer_gather_in_graph"] = {"tokens_per_s": nb / t, "ms_per_step": t * 1e3}
+                else:
+                    fig["peer_gather_in_graph"] = {"error": "a peer gather gave up waiting for a flag"}
+                    res["peer_gather"]["validated_against_collective"] = False
+            coll = qp.shard.make_gatherer(world, device)
+            token, _ = make_token(qp, torch, layers, xs, nb, device, launch="multi", gather=coll)
+            t = timed(token, False)
+            log(f"batch {nb}: collective between eager launches {t * 1e3:.2f} ms per step")
+            fig["collective_eager"] = {"tokens_per_s": nb / t, "ms_per_step": t * 1e3}
+            valid = [v for v in fig.values() if "tokens_per_s" in v]
+            best = max(valid, key=lambda v: v["tokens_per_s"])
+            fig["value"] = best["tokens_per_s"]
+            fig["unit"] = "tokens/s"
+            fig["ms_per_step"] = best["ms_per_step"]
+            fig["roofline_frac_per_gpu"] = abytes / (best["ms_per_step"] / 1e3) / 1e9 / HBM_PEAK_GBS
+            res[f"bs{nb}"] = fig
+    finally:
+        if peer is not None:
+            peer.close()
     return res
 
 

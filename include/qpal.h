@@ -59,8 +59,10 @@ typedef struct qpal_tcq_job {
     int out_zeroed;    /* 1: the caller guarantees out is all zeros (e.g. pre-zeroed by an earlier launch, below):
                           a split-K job then needs no memset node of its own, and the planner may let two workgroups share
                           a row (pair mode, csrc/tc_kernels.h TcParams: +3 % tokens/s on a Llama-8B token) — both use
-                          float atomics into the zeroed buffer; with at most two adders per element the result is
-                          order-independent */
+                          float atomics into the zeroed buffer; with at most two adders per element of a ZEROED output the
+                          result is order-independent (0 + a + b).  A job that accumulates (`accumulate`: out += ...) may be
+                          split or paired as well: its adders land on the live value h, and (h + a) + b != (h + b) + a in
+                          fp32 — such an output is reproducible to rounding, not to the bit */
     const void *wscale; /* fp16 [m] or NULL: fused epilogue out[b][r] = acc * wscale[r] * oscale — the
                           `* Wscale * scale` that follows every quantized linear in the reference's incoherent
                           wrappers (lib/linear/incoherent_linear.py:83-99, 107, 327-337, 496-503) */

@@ -118,7 +118,8 @@ class PeerGatherer:
     rank can start token T+1 while a slow peer still runs token T, but it cannot pass the token's LAST call site before that
     peer has launched its own last call — which is stream-ordered behind the peer's consumers of every EARLIER site.  So the
     view returned for call site s may be overwritten only once its consumers are done, PROVIDED s is not the only site:
-    a token needs >= 2 call sites (checked by new_token()); with a single site per token use two gatherers alternately.
+    a token needs >= 2 call sites (checked by finish_token() on the token just issued — call it at the end of a token that is
+    captured and replayed — and by the next new_token()); with a single site per token use two gatherers alternately.
     Call `new_token()` before re-running or capturing a token so that the same call sites map to the same slots.
     RCCL's all_gather (`make_gatherer`) stays the correctness baseline: `validate()` compares the two on this node."""
 
@@ -174,7 +175,21 @@ class PeerGatherer:
         # torch views of this rank's own allocations (results are views into bufs; error() reads ws)
         self.bufs = _tensor_from_ptr(self._bufs_ptr, nbuf, self.device, self)
         self.ws = _tensor_from_ptr(self._ws_ptr, nws, self.device, self)
+        # (a view, not a copy: as_tensor on another device than the one it deduces from the pointer would copy silently, and the
+        # gather's results and its error word would then be read from the copy)
+        if self.bufs.data_ptr() != self._bufs_ptr or self.ws.data_ptr() != self._ws_ptr:
+            raise nat.QpalError("PeerGatherer: the torch views of the shared allocations are copies, not views")
         dist.barrier(group=group)
+
+    def __del__(self):
+        # best effort: unmap the peers' allocations of a gatherer nobody closed (no barrier here: close() is the orderly way)
+        try:
+            lib = self.nat.lib()
+            for p in getattr(self, "_opened", []):
+                lib.qpal_ipc_close(p)
+            self._opened = []
+        except Exception:
+            pass
 
     def close(self):
         """Unmap the peers' allocations and free this rank's (after a barrier: nobody may still be writing here)."""
@@ -190,12 +205,22 @@ class PeerGatherer:
             self._own = []
         self.bufs = self.ws = None  # views of freed memory
 
+    _ONE_SITE = ("PeerGatherer: a token with ONE call site may overwrite a slice a slow peer still reads; use >= 2 "
+                 "call sites per token (or two gatherers alternately)")
+
     def new_token(self):
-        if self._next == 1 and self._sites_last_token == 1:
-            raise RuntimeError("PeerGatherer: a token with ONE call site may overwrite a slice a slow peer still reads; use >= 2 "
-                               "call sites per token (or two gatherers alternately)")
+        """Start of a token's call sites.  A token that ended with ONE call site is refused HERE, i.e. before a second such
+        token can be issued (and finish_token() refuses it at once — call it at the end of a token that is captured once and
+        replayed: new_token() runs only at capture)."""
+        if self._next == 1:
+            raise RuntimeError(self._ONE_SITE)
         self._sites_last_token = self._next if self._next else self._sites_last_token
         self._next = 0
+
+    def finish_token(self):
+        """End of a token: the >= 2 call sites rule checked on the token just issued (a captured graph replays exactly this)."""
+        if self._next == 1:
+            raise RuntimeError(self._ONE_SITE)
 
     def __call__(self, y):
         import ctypes
@@ -244,6 +269,7 @@ class PeerGatherer:
         dev = self.device
         saved = (self._next, self._sites_last_token, dict(self._widths))
         self._widths = {}  # the validation's own slice widths for the two slots it borrows
+        self._next = 0
         srcs = [torch.empty(n, width, dtype=dtype, device=dev) for _ in range(2)]
         ok = True
 
