@@ -255,15 +255,20 @@ struct TcqCodec {
         }
     }
 
-    // half2 weight pair of vector (G, I)
+    // byte address, inside the codebook image, of the half2 weight pair of vector (G, I): the VALU half of the decode
     template <int G, int I>
-    static __device__ __forceinline__ uint32_t pair(const uint32_t *lds, uint32_t laneoff, const uint32_t (&w)[NW],
-                                                    uint32_t next_head) {
+    static __device__ __forceinline__ uint32_t addr(uint32_t laneoff, const uint32_t (&w)[NW], uint32_t next_head) {
         const uint32_t s = window<G, I>(w, next_head);
         uint32_t h;
         asm("v_mad_u32_u24 %0, %1, %1, %1" : "=v"(h) : "v"(s));  // s*s + s: low 16 bits exact
         if constexpr (XS == 1) asm("v_add_u32 %0, %1, %1" : "=v"(h) : "v"(h));  // (h << 1 as a shift is a half-rate op)
-        const uint32_t a = (h & HMASK) | laneoff;
+        return (h & HMASK) | laneoff;
+    }
+    // half2 weight pair of vector (G, I)
+    template <int G, int I>
+    static __device__ __forceinline__ uint32_t pair(const uint32_t *lds, uint32_t laneoff, const uint32_t (&w)[NW],
+                                                    uint32_t next_head) {
+        const uint32_t a = addr<G, I>(laneoff, w, next_head);
 #ifdef QPAL_KO_GATHER  // timing experiment (tc_gemm.h): the address instead of the gathered entry
         return a;
 #else
@@ -323,13 +328,25 @@ struct LutCodec {
     static __device__ __forceinline__ uint32_t head(const uint32_t (&)[NW]) { return 0u; }
 
     template <int POS, int NB_>
-    static __device__ __forceinline__ uint32_t gather(const uint32_t *lds, uint32_t laneoff, const uint32_t (&w)[NW]) {
+    static __device__ __forceinline__ uint32_t gather_addr(uint32_t laneoff, const uint32_t (&w)[NW]) {
         // NB_ index bits at LE bit POS; stay inside one dword when possible (single v_bfe_u32)
         uint32_t e;
         if constexpr ((POS & 31) + NB_ <= 32) e = __builtin_amdgcn_ubfe(w[POS >> 5], POS & 31, NB_);
         else e = __builtin_amdgcn_ubfe(ext32<POS>(w), 0, NB_);
-        const uint32_t a = (e << (LOG2C + 2)) | laneoff;
-        return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + a);
+        return (e << (LOG2C + 2)) | laneoff;
+    }
+    template <int POS, int NB_>
+    static __device__ __forceinline__ uint32_t gather(const uint32_t *lds, uint32_t laneoff, const uint32_t (&w)[NW]) {
+        return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + gather_addr<POS, NB_>(laneoff, w));
+    }
+    // byte address of the pair (G, I) inside the image, for the codes that decode a pair with ONE gather (gemv_step_pipe)
+    template <int G, int I>
+    static __device__ __forceinline__ uint32_t addr(uint32_t laneoff, const uint32_t (&w)[NW], uint32_t)
+        requires(VEC == 2 || PAIR)
+    {
+        constexpr int r = I >> 2, j = I & 3;
+        if constexpr (VEC == 2) return gather_addr<r * 16 * BITS + G * 4 * BITS + j * BITS, BITS>(laneoff, w);
+        else return gather_addr<r * 32 * BITS + G * 8 * BITS + 2 * j * BITS, 2 * BITS>(laneoff, w);
     }
 
     template <int G, int I>
@@ -487,6 +504,50 @@ __device__ __forceinline__ void gemv_step(const uint32_t *lut, uint32_t laneoff,
     });
 }
 
+// Software-pipelined form of the step (QPAL_GEMV_PIPE, batch group count 1, codecs with `addr`): the compiler's own order per
+// tile group is  8 addresses (VALU) -> 8 gathers -> wait -> 2 MFMAs,  i.e. a wave has no VALU work while its gathers are in flight
+// and no gathers in flight while it computes addresses; here the addresses of group g + 1 are computed between the gathers of
+// group g and the MFMAs that consume them (order pinned by sched_barrier fences).
+#ifndef QPAL_GEMV_PIPE
+#define QPAL_GEMV_PIPE 1
+#endif
+template <class Codec>
+constexpr bool has_addr_v = requires(const uint32_t (&w)[Codec::NW]) { Codec::template addr<0, 0>(0u, w, 0u); };
+template <class Codec>
+__device__ __forceinline__ void gemv_step_pipe(const uint32_t *lut, uint32_t laneoff, const uint32_t (&w)[Codec::NW],
+                                               const u32x4 (&xb)[1][2], Acc<1> &acc) {
+    const char *l8 = reinterpret_cast<const char *>(lut);
+    uint32_t ac[8], an[8];
+    auto addrs = [&](auto gc, uint32_t(&a)[8]) {
+        constexpr int g = decltype(gc)::value;
+        uint32_t nh = 0u;
+        if constexpr (Codec::kNeedsNext) nh = row16_next(Codec::template head<g>(w));
+        static_for<0, 8>([&](auto ic) { a[decltype(ic)::value] = Codec::template addr<g, decltype(ic)::value>(laneoff, w, nh); });
+    };
+    addrs(std::integral_constant<int, 0>{}, ac);
+    static_for<0, 4>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int ksub = g >> 1, msub = g & 1;
+        uint32_t d[8];
+        static_for<0, 8>([&](auto ic) { d[decltype(ic)::value] = *reinterpret_cast<const uint32_t *>(l8 + ac[decltype(ic)::value]); });
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g < 3) addrs(std::integral_constant<int, g + 1>{}, an);
+        __builtin_amdgcn_sched_barrier(0);
+        // fragment order (jh, isB): i = jl + 2*jh + 4*isB
+        acc.v[0][msub * 2 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, u32x4{d[0], d[4], d[2], d[6]}),
+                                                                        __builtin_bit_cast(half8_t, xb[0][ksub]), acc.v[0][msub * 2 + 0], 0, 0, 0);
+        acc.v[0][msub * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, u32x4{d[1], d[5], d[3], d[7]}),
+                                                                        __builtin_bit_cast(half8_t, xb[0][ksub]), acc.v[0][msub * 2 + 1], 0, 0, 0);
+        if constexpr (g < 3) static_for<0, 8>([&](auto ic) { ac[decltype(ic)::value] = an[decltype(ic)::value]; });
+    });
+}
+template <class Codec, int NBG>
+__device__ __forceinline__ void gemv_step_any(const uint32_t *lut, uint32_t laneoff, const uint32_t (&w)[Codec::NW],
+                                              const u32x4 (&xb)[NBG][2], Acc<NBG> &acc) {
+    if constexpr (QPAL_GEMV_PIPE != 0 && NBG == 1 && has_addr_v<Codec>) gemv_step_pipe<Codec>(lut, laneoff, w, xb, acc);
+    else gemv_step<Codec, NBG>(lut, laneoff, w, xb, acc);
+}
+
 // steps [s0, s1) of one stream; `w` already holds step s0 (loaded before the codebook image was built).
 // Two register sets ping-pong (loop unrolled by 2) so the one-step-ahead prefetch costs no copies.
 // Deeper prefetch, measured and not kept.  Round 3: two or three steps in flight with every wave's steps padded to whole rounds of
@@ -508,7 +569,7 @@ __device__ __forceinline__ void gemv_run(uint32_t (&w)[Codec::NW], const uint32_
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's decode (hipcc sinks it otherwise)
             u32x4 xb[NBG][2];
             load_step_x<XLDS, NBG>(sv, xg, xs, k, n, zero_off, s, lane, xb);
-            gemv_step<Codec, NBG>(lut, laneoff, w, xb, acc);
+            gemv_step_any<Codec, NBG>(lut, laneoff, w, xb, acc);
         }
         if (s + 1 < s1) {
             const int sn = s + 2 < s1 ? s + 2 : s + 1;
@@ -516,7 +577,7 @@ __device__ __forceinline__ void gemv_run(uint32_t (&w)[Codec::NW], const uint32_
             __builtin_amdgcn_sched_barrier(0);
             u32x4 xb[NBG][2];
             load_step_x<XLDS, NBG>(sv, xg, xs, k, n, zero_off, s + 1, lane, xb);
-            gemv_step<Codec, NBG>(lut, laneoff, wb, xb, acc);
+            gemv_step_any<Codec, NBG>(lut, laneoff, wb, xb, acc);
         }
     }
 }
