@@ -82,8 +82,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
         sc[t] = acc;
         mx = acc > mx ? acc : mx;
     }
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) { const float o = __shfl_xor(mx, sft, 64); mx = o > mx ? o : mx; }
+    mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     mx = red[0];
@@ -94,8 +93,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
         sc[t] = e;
         sum += e;
     }
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) sum += __shfl_xor(sum, sft, 64);
+    sum = wave_sum(sum);
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
     sum = red[4] + red[5] + red[6] + red[7];
@@ -279,8 +277,7 @@ __device__ __forceinline__ void attn_rope_head(const AttnRopeParams &p, float *s
             a = fdot2(kv[u].y, qv.y, a);
             a = fdot2(kv[u].z, qv.z, a);
             a = fdot2(kv[u].w, qv.w, a);
-#pragma unroll
-            for (int sft = 1; sft < LPR; sft <<= 1) a += __shfl_xor(a, sft, 64);
+            a = group_sum<LPR>(a);
             a *= p.scale;
             if (t < pos) {
                 if (sl == 0) sc[t] = a;
@@ -297,14 +294,12 @@ __device__ __forceinline__ void attn_rope_head(const AttnRopeParams &p, float *s
             a = fdot2(kn.z, qv.z, a);
             a = fdot2(kn.w, qv.w, a);
         }
-#pragma unroll
-        for (int sft = 1; sft < LPR; sft <<= 1) a += __shfl_xor(a, sft, 64);
+        a = group_sum<LPR>(a);
         a *= p.scale;
         if (lane == 0) sc[pos] = a;
         if (grp == 0) mx = a > mx ? a : mx;
     }
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) { const float o = __shfl_xor(mx, sft, 64); mx = o > mx ? o : mx; }
+    mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     mx = red[0];
@@ -316,8 +311,7 @@ __device__ __forceinline__ void attn_rope_head(const AttnRopeParams &p, float *s
         sc[t] = e;
         sum += e;
     }
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) sum += __shfl_xor(sum, sft, 64);
+    sum = wave_sum(sum);
     if (lane == 0) red[NW + wave] = sum;
     __syncthreads();
     sum = 0.f;
@@ -542,16 +536,14 @@ __global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSpli
                 a = fdot2(kn.y, qv.y, a);
                 a = fdot2(kn.z, qv.z, a);
                 a = fdot2(kn.w, qv.w, a);
-#pragma unroll
-                for (int sft = 1; sft < LPR; sft <<= 1) a += __shfl_xor(a, sft, 64);
+                a = group_sum<LPR>(a);
                 if (lane == 0) park[h] = a * p.scale;
             }
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {  // maximum over the 16 positions (lanes) of this lane's head group, per wave
             float m = mx4[r];
-#pragma unroll
-            for (int sft = 8; sft >= 1; sft >>= 1) { const float o = __shfl_xor(m, sft, 64); m = o > m ? o : m; }
+            m = group_max<16>(m);
             if (mi == 0 && 4 * mq + r < REP) red[(4 * mq + r) * NW + wave] = m;
         }
         __syncthreads();
@@ -573,8 +565,7 @@ __global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSpli
                 sc[hh * CL + t] = e;
                 sm += e;
             }
-#pragma unroll
-            for (int sft = 32; sft >= 1; sft >>= 1) sm += __shfl_xor(sm, sft, 64);
+            sm = wave_sum(sm);
             if (lane == 0) red[NW * REP + wave] = sm;
         }
         __syncthreads();
@@ -716,8 +707,7 @@ __global__ __launch_bounds__(1024) void lm_head_argmax_kernel(const LmHeadParams
         const float v = p.h[i];
         ss += v * v;
     }
-#pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+    ss = wave_sum(ss);
     if (lane == 0) red[wave] = ss;
     __syncthreads();
     float tot = 0.f;
@@ -758,8 +748,7 @@ __global__ __launch_bounds__(1024) void lm_head_argmax_kernel(const LmHeadParams
                 a = fdot2(wv[u][c].z, xr[c].z, a);
                 a = fdot2(wv[u][c].w, xr[c].w, a);
             }
-#pragma unroll
-            for (int sh = 32; sh >= 1; sh >>= 1) a += __shfl_xor(a, sh, 64);
+            a = wave_sum(a);
             if (r < p.vocab) {
                 if (p.logits && lane == 0) p.logits[r] = a;
                 if (a > best) best = a, besti = r;  // rows ascend within a wave: strict > keeps the lowest index

@@ -242,8 +242,7 @@ __global__ __launch_bounds__(NT) void had_kernel(HadParams p) {
             else if (p.rms_eps > 0.f) {  // (the host gives an RMSNorm launch at least two passes)
                 float ss = 0.f;
                 had_pass_r<true, false, NT>(r, p, buf, 0, row, col0, tid, &ss);
-#pragma unroll
-                for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+                ss = wave_sum(ss);
                 float *part = buf + p.hd + (p.hd >> 5) + 1;
                 if (lane == 0) part[wave] = ss;
                 __syncthreads();
@@ -440,8 +439,7 @@ __global__ __launch_bounds__(256) void had_split_mfma_kernel(HadParams p) {
     }
     float mul = 1.0f;
     if constexpr (RMS) {
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+        ss = wave_sum(ss);
         if (lane == 0) part[ct] = ss;
     }
     __syncthreads();

@@ -103,4 +103,61 @@ __device__ __forceinline__ float wave_xor_add(float v, int mask) {
     return v + __shfl_xor(v, mask, 64);
 }
 
+// Value of lane ^ MASK as ONE VALU instruction (DPP) where the hardware has one — `__shfl_xor` compiles to `ds_bpermute_b32`, an
+// LDS-pipe operation with the full LDS round trip (round 4: the GEMV epilogue's four dependent exchange rounds were 0.5 us of every
+// launch, queued behind the other waves' codebook gathers).  MASK 1, 2: quad_perm; 7, 15: row_half_mirror / row_mirror (inside a
+// reduction tree they do what xor 4 / xor 8 do); anything else falls back to the permute.
+template <int MASK>
+__device__ __forceinline__ float lane_xor(float v) {
+    const int i = __builtin_bit_cast(int, v);
+    if constexpr (MASK == 1) return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(i, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true));
+    else if constexpr (MASK == 2) return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(i, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true));
+    else if constexpr (MASK == 7) return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(i, 0x141 /* row_half_mirror */, 0xF, 0xF, true));
+    else if constexpr (MASK == 15) return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(i, 0x140 /* row_mirror */, 0xF, 0xF, true));
+    else return __shfl_xor(v, MASK, 64);
+}
+// Sum over the 64 lanes of a wave, the same value in every lane: four DPP steps inside the rows of 16, then the four row totals
+// through scalar registers (v_readlane) — ~11 VALU instructions against six dependent LDS round trips of the shuffle tree.
+// (The summation ORDER differs from the xor tree's: not for results that must be bit-identical to an earlier build.)
+// sum / max over the aligned group of G lanes a lane belongs to, the same value in all of them: DPP only up to G = 16
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "a power of two");
+    if constexpr (G >= 2) v += lane_xor<1>(v);
+    if constexpr (G >= 4) v += lane_xor<2>(v);
+    if constexpr (G >= 8) v += lane_xor<7>(v);
+    if constexpr (G >= 16) v += lane_xor<15>(v);
+    if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);  // (across rows: the permute)
+    if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "inside one row of 16 lanes");
+    if constexpr (G >= 2) v = fmaxf(v, lane_xor<1>(v));
+    if constexpr (G >= 4) v = fmaxf(v, lane_xor<2>(v));
+    if constexpr (G >= 8) v = fmaxf(v, lane_xor<7>(v));
+    if constexpr (G >= 16) v = fmaxf(v, lane_xor<15>(v));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = group_max<16>(v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += lane_xor<1>(v);
+    v += lane_xor<2>(v);
+    v += lane_xor<7>(v);
+    v += lane_xor<15>(v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 }  // namespace qpal

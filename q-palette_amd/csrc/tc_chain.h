@@ -548,8 +548,8 @@ __global__ __launch_bounds__(kChainThreads) void tc_chain_kernel(const TcMultiPa
             static_for<0, 4>([&](auto ac) {
                 constexpr int a = decltype(ac)::value;
                 const float4_t dd = acc.v[0][a];
-                const float v0 = dd[0] + __shfl_xor(dd[1], 1, 64);
-                const float v1 = dd[2] + __shfl_xor(dd[3], 1, 64);
+                const float v0 = dd[0] + lane_xor<1>(dd[1]);
+                const float v1 = dd[2] + lane_xor<1>(dd[3]);
                 if (writer) {
                     dst[8 * a] = v0;
                     dst[8 * a + 1] = v1;

@@ -328,8 +328,8 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
                 static_for<0, 4>([&](auto ac) {
                     constexpr int a = decltype(ac)::value;
                     const float4_t d = acc.v[grp][a];
-                    const float v0 = d[0] + __shfl_xor(d[1], 1, 64);
-                    const float v1 = d[2] + __shfl_xor(d[3], 1, 64);
+                    const float v0 = d[0] + lane_xor<1>(d[1]);
+                    const float v1 = d[2] + lane_xor<1>(d[3]);
                     if ((cidx & 1) == 0) *reinterpret_cast<float2 *>(scr + (cidx >> 1) * 32 + 8 * a + 2 * q) = float2{v0, v1};
                 });
                 // (wave-private scratch: LDS operations of one wave complete in order)

@@ -747,8 +747,7 @@ __device__ __forceinline__ void rot_stage1_regs(const u32x4 (&rq)[2][4], bool f3
     }
     wht64_wg_stage1_pre(wave, lane, d1buf, a[0], a[1]);
     if (rms) {
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+        ss = wave_sum(ss);
         if (lane == 0) part[wave] = ss;
     }
 }
@@ -1216,8 +1215,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                         if (p.x_rot == 4) wht64_wg_stage1<4>(wave, lane, d1buf, load_row(p.x));
                         else wht64_wg_stage1<2>(wave, lane, d1buf, load_row(p.x));
                         if (rms && wave < p.x_rot) {
-#pragma unroll
-                            for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+                            ss = wave_sum(ss);
                             if (lane == 0) part[wave] = ss;
                         }
                     }
@@ -1350,8 +1348,8 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                 static_for<0, 4>([&](auto ac) {  // rows 16*msub + 8*jl + 2q + {0,1}
                     constexpr int a = decltype(ac)::value;
                     const float4_t d = acc.v[grp][a];
-                    const float v0 = d[0] + __shfl_xor(d[1], 1, 64);
-                    const float v1 = d[2] + __shfl_xor(d[3], 1, 64);
+                    const float v0 = d[0] + lane_xor<1>(d[1]);
+                    const float v1 = d[2] + lane_xor<1>(d[3]);
                     if (writer) {
                         dst[8 * a] = v0;
                         dst[8 * a + 1] = v1;
