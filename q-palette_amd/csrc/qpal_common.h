@@ -106,7 +106,7 @@ __device__ __forceinline__ float wave_xor_add(float v, int mask) {
 // Value of lane ^ MASK as ONE VALU instruction (DPP) where the hardware has one — `__shfl_xor` compiles to `ds_bpermute_b32`, an
 // LDS-pipe operation with the full LDS round trip (round 4: the GEMV epilogue's four dependent exchange rounds were 0.5 us of every
 // launch, queued behind the other waves' codebook gathers).  MASK 1, 2: quad_perm; 7, 15: row_half_mirror / row_mirror (inside a
-// reduction tree they do what xor 4 / xor 8 do); anything else falls back to the permute.
+// reduction tree they do what xor 4 / xor 8 do); 16, 32: the gfx950 permlane swaps; anything else falls back to the permute.
 template <int MASK>
 __device__ __forceinline__ float lane_xor(float v) {
     const int i = __builtin_bit_cast(int, v);
@@ -114,7 +114,15 @@ __device__ __forceinline__ float lane_xor(float v) {
     else if constexpr (MASK == 2) return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(i, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true));
     else if constexpr (MASK == 7) return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(i, 0x141 /* row_half_mirror */, 0xF, 0xF, true));
     else if constexpr (MASK == 15) return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(i, 0x140 /* row_mirror */, 0xF, 0xF, true));
-    else return __shfl_xor(v, MASK, 64);
+    else if constexpr (MASK == 16) {
+        // gfx950 v_permlane16_swap: rows 1 / 3 of the first operand trade places with rows 0 / 2 of the second.  With v in both:
+        // r[0] = [row0, row0, row2, row2], r[1] = [row1, row1, row3, row3] -> lane ^ 16 is r[1] in the even rows, r[0] in the odd ones
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)i, (unsigned)i, false, false);
+        return __builtin_bit_cast(float, (__lane_id() & 16) ? r[0] : r[1]);
+    } else if constexpr (MASK == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)i, (unsigned)i, false, false);  // (likewise for the wave's halves)
+        return __builtin_bit_cast(float, (__lane_id() & 32) ? r[0] : r[1]);
+    } else return __shfl_xor(v, MASK, 64);
 }
 // Sum over the 64 lanes of a wave, the same value in every lane: four DPP steps inside the rows of 16, then the four row totals
 // through scalar registers (v_readlane) — ~11 VALU instructions against six dependent LDS round trips of the shuffle tree.
@@ -127,8 +135,8 @@ __device__ __forceinline__ float group_sum(float v) {
     if constexpr (G >= 4) v += lane_xor<2>(v);
     if constexpr (G >= 8) v += lane_xor<7>(v);
     if constexpr (G >= 16) v += lane_xor<15>(v);
-    if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);  // (across rows: the permute)
-    if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
+    if constexpr (G >= 32) v += lane_xor<16>(v);
+    if constexpr (G >= 64) v += lane_xor<32>(v);
     return v;
 }
 template <int G>

@@ -129,7 +129,7 @@ __device__ __forceinline__ void rot_k28_impl(const RotK28Regs &pre_regs, bool ha
             float w4[4] = {s0 + s2, s1 + s3, s0 - s2, s1 - s3};
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float o = __shfl_xor(w4[r], 16, 64);
+                const float o = lane_xor<16>(w4[r]);
                 const float t = (q & 1u) ? o - w4[r] : w4[r] + o;
                 const int col = (4 * (int)(q & 1u) + r) * 64 + 16 * (int)ct + (int)j;
                 *reinterpret_cast<_Float16 *>(tb + col * kTbRow + 2 * i_row) = (_Float16)(t * pre);

@@ -218,11 +218,7 @@ __global__ __launch_bounds__(1024) void simt_kernel(const SimtParams p) {
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 float v = acc[b];
-                v = wave_xor_add(v, 1);
-                v = wave_xor_add(v, 2);
-                v = wave_xor_add(v, 4);
-                v = wave_xor_add(v, 8);
-                v = wave_xor_add(v, 16);
+                v = group_sum<32>(v);  // (DPP / permlane swaps: the same tree as xor 1, 2, 4, 8, 16, bit for bit, without the LDS round trips)
                 if (t == 0 && row_ok && b < p.n) {
                     const _Float16 hv = (_Float16)v;
                     p.out[(long)b * p.m + row] = __builtin_bit_cast(uint16_t, hv);
@@ -333,12 +329,8 @@ __global__ __launch_bounds__(1024) void simt_gemv_kernel(const SimtParams p, con
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             float v = acc[b];
-            v = wave_xor_add(v, 1);
-            v = wave_xor_add(v, 2);
-            v = wave_xor_add(v, 4);
-            v = wave_xor_add(v, 8);
-            v = wave_xor_add(v, 16);
-            if (split) v = wave_xor_add(v, 32);
+            v = group_sum<32>(v);
+            if (split) v += lane_xor<32>(v);
             const int row = split ? rp : rp * 2 + half;
             if (t == 0 && (!split || half == 0) && row < p.m && b < p.n)
                 p.out[(long)b * p.m + row] = __builtin_bit_cast(uint16_t, (_Float16)v);
