@@ -1101,6 +1101,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                 load_step_w<C1::NW>(sv1, s0, lane, w.a);
             }
         }
+        QPAL_STAMP(1);  // (the first weights are requested)
         if constexpr (kEarly) {
             if (FIRST && early) {  // early staging, part 2b: registers -> LDS
                 const int total = en * ek;
@@ -1123,13 +1124,13 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                 }
                 cur_x = ex;
                 cur_tab = etab;
+                QPAL_STAMP(2);  // (staged; stamp 3 is behind the barrier)
                 __syncthreads();
             }
         }
         if (FIRST && mp.zero_chunks > 0) {  // pre-zero a buffer for a later split-K launch on this stream
             for (int i = blockIdx.x * NT + tid; i < mp.zero_chunks; i += gridDim.x * NT) mp.zero[i] = u32x4{0u, 0u, 0u, 0u};
         }
-        QPAL_STAMP(1);
         if (p.tab != cur_tab || (x_lds && p.x != cur_x)) {  // workgroup-uniform
             if (x_lds && p.x != cur_x) {
                 const int total = p.n * p.k;  // multiple of 8 halves
