@@ -57,7 +57,7 @@ __global__ __launch_bounds__(1024) void calib_decode_kernel(const void *tab, uin
 #pragma nounroll
     for (int it = 0; it < iters; it++) {
         u32x4 xb[1][2];
-        load_step_x<true, 1>(sv, xs, xs, 4096, 1, 4096, it & 7, lane, xb);
+        load_step_x<1, 1>(sv, xs, xs, 4096, 1, 4096, it & 7, lane, xb);
         gemv_step_any<Codec, 1>(lut, laneoff, w, xb, acc);
 #pragma unroll
         for (int i = 0; i < Codec::NW; i++) asm volatile("" : "+v"(w[i]));  // "new packed words": nothing is hoisted, no instruction

@@ -120,6 +120,9 @@ struct TcMultiParams {
 #ifndef QPAL_BUILD_U
 #define QPAL_BUILD_U 1
 #endif
+#ifndef QPAL_XPERM_PLAIN  // the permuted x layout in the plain GEMV kernels (see xs_put)
+#define QPAL_XPERM_PLAIN 1
+#endif
 #ifndef QPAL_ROT_BUILD_U  // the image build of the rotating kernels' builder waves (12 of 16 at k = 4096) only
 #define QPAL_ROT_BUILD_U 1
 #endif
@@ -412,21 +415,23 @@ struct Acc {
 // Layout of the staged activations (batch <= 8, XLDS): inside every block of 32 halves (one supertile column) the eight
 // 4-half pieces p0..p7 are stored as [p0 p2 p4 p6 | p1 p3 p5 p7] — the lane of column half u reads 16 contiguous halves at
 // 16 u.  xs_put stores the 16-byte chunk of halves [i, i + 8) (i a multiple of 8); xs_index maps one half.
+// XP (the plain kernels: ROT 0 / 3): the permuted layout; the rotating kernels keep the plain one (their second stage writes single
+// halves through xs_index: the permutation's index arithmetic costs them more than the wider reads save — round 4,
+// profiles/r04_ab_xperm.txt: plain token +0.4…+0.9 %, wrapper token -1.4 % with the permutation everywhere).
+template <bool XP>
 __device__ __forceinline__ void xs_put(uint16_t *xs, int i, u32x4 v) {
-#ifdef QPAL_XPERM
-    uint16_t *d = xs + (i & ~31) + ((i >> 3) & 3) * 4;
-    *reinterpret_cast<u32x2 *>(d) = u32x2{v.x, v.y};
-    *reinterpret_cast<u32x2 *>(d + 16) = u32x2{v.z, v.w};
-#else
-    *reinterpret_cast<u32x4 *>(xs + i) = v;
-#endif
+    if constexpr (XP) {
+        uint16_t *d = xs + (i & ~31) + ((i >> 3) & 3) * 4;
+        *reinterpret_cast<u32x2 *>(d) = u32x2{v.x, v.y};
+        *reinterpret_cast<u32x2 *>(d + 16) = u32x2{v.z, v.w};
+    } else {
+        *reinterpret_cast<u32x4 *>(xs + i) = v;
+    }
 }
+template <bool XP>
 __device__ __forceinline__ int xs_index(int i) {
-#ifdef QPAL_XPERM
-    return (i & ~31) | (((i >> 2) & 1) << 4) | (((i >> 3) & 3) << 2) | (i & 3);
-#else
-    return i;
-#endif
+    if constexpr (XP) return (i & ~31) | (((i >> 2) & 1) << 4) | (((i >> 3) & 3) << 2) | (i & 3);
+    else return i;
 }
 
 // MFMA B operand of a step.  Lane (kb = lane>>4, c = lane&15) supplies, for batch row b = 8*grp + (c>>1) and
@@ -435,7 +440,8 @@ __device__ __forceinline__ int xs_index(int i) {
 // XLDS (batch <= 8 only): x was staged in LDS as [n][k] followed by a 64-byte zero pad (dead supertile
 // columns of a partial last step read the pad); otherwise x is read from global memory (L2) and dead lanes
 // are zeroed by select.
-template <bool XLDS, int NBG>
+// XLDS: 0 x from global memory, 1 staged in LDS, 2 staged in LDS in the permuted layout (xs_put<true>)
+template <int XLDS, int NBG>
 __device__ __forceinline__ void load_step_x(const StreamView &sv, const uint16_t *xg, const uint16_t *xs, int k, int n,
                                             int zero_off, int step, int lane, u32x4 (&xb)[NBG][2]) {
     const int sc = step * 4 + (lane >> 4);
@@ -446,14 +452,13 @@ __device__ __forceinline__ void load_step_x(const StreamView &sv, const uint16_t
         int b = 8 * grp + (c >> 1);
         b = b < n ? b : n - 1;
         const int off = b * k + sv.col0 + sc * 32 + 4 * (c & 1);
-        if constexpr (XLDS) {
-#ifdef QPAL_XPERM
-            // staged x is PERMUTED inside every 32-half block (xs_put below): the four 8-byte pieces a lane needs are
+        if constexpr (XLDS == 2) {
+            // staged x is PERMUTED inside every 32-half block (xs_put<true>): the four 8-byte pieces a lane needs are
             // contiguous, so the B operand of a step is two ds_read_b128 (4 LDS cycles each) instead of two ds_read2_b64 (8)
             const uint16_t *row = xs + (live ? off + 12 * (c & 1) : zero_off);
             xb[grp][0] = *reinterpret_cast<const u32x4 *>(row);
             xb[grp][1] = *reinterpret_cast<const u32x4 *>(row + 8);
-#else
+        } else if constexpr (XLDS == 1) {
             const uint16_t *row = xs + (live ? off : zero_off);
 #pragma unroll
             for (int ksub = 0; ksub < 2; ksub++) {
@@ -461,7 +466,6 @@ __device__ __forceinline__ void load_step_x(const StreamView &sv, const uint16_t
                 const u32x2 hi = *reinterpret_cast<const u32x2 *>(row + 16 * ksub + 8);
                 xb[grp][ksub] = u32x4{lo.x, lo.y, hi.x, hi.y};
             }
-#endif
         } else {
             const uint16_t *row = xg + (live ? off : 0);
 #pragma unroll
@@ -557,7 +561,7 @@ __device__ __forceinline__ void gemv_step_any(const uint32_t *lut, uint32_t lane
 // the three bodies still covers the newer step); restricted to chunks of >= 3 (>= 5) steps, i.e. gate | up and down only:
 // gate | up +-0, down +0.9 us (+0.1).  The stamps' 0.36 us per step inside gate | up against 0.31 on register-resident words
 // is therefore not load latency a deeper register prefetch recovers.
-template <class Codec, bool XLDS, int NBG>
+template <class Codec, int XLDS, int NBG>
 __device__ __forceinline__ void gemv_run(uint32_t (&w)[Codec::NW], const uint32_t *lut, uint32_t laneoff,
                                          const StreamView &sv, const uint16_t *xg, const uint16_t *xs, int k, int n,
                                          int zero_off, int s0, int s1, int lane, Acc<NBG> &acc) {
@@ -785,6 +789,8 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     // across their seven decode loops' set-up spilled 16-28 VGPRs, and a kernel that touches scratch at all pays ~1 us per
     // launch — without early staging they have no spills and the q | k | v launch of a mixed-scheme model takes 7.1 instead of
     // 8.3 us (llama3.1-8b_figure1c 651 -> 707 tok/s, mem3p25 678 -> 722, one box: profiles/r03_ab_any_spills.txt).
+    constexpr bool kXPerm = QPAL_XPERM_PLAIN != 0 && (ROT == 0 || ROT == 3);  // staged x in the permuted layout (xs_put)
+    constexpr int kXL = kXPerm ? 2 : 1;
     constexpr bool PAIRK = ROT == 3;  // plain kernel that also understands pair-mode jobs (sk == -1, TcParams)
 #ifndef QPAL_ANY_EARLY
 #define QPAL_ANY_EARLY 1  // round 4: with the early loads outside the compiler's bookkeeping (inline asm) and the first item as its own
@@ -1108,7 +1114,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
 #pragma unroll
                 for (int r = 0; r < XR; r++) {
                     const int i = tid * 8 + r * (NT * 8);
-                    if (i < total + 32) xs_put(xs, i, i < total ? exr[r] : u32x4{0u, 0u, 0u, 0u});
+                    if (i < total + 32) xs_put<kXPerm>(xs, i, i < total ? exr[r] : u32x4{0u, 0u, 0u, 0u});
                 }
 #pragma unroll
                 for (int r = 0; r < EV; r++) {
@@ -1145,13 +1151,13 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                     if (from_regs) {
                         if constexpr (kRot28Early) {
                             rot_k28_regs(r28, p.x_su != nullptr, p.x_pre, p.x_post, xs, reinterpret_cast<unsigned char *>(lut), wave, lane,
-                                         [](int i) { return xs_index(i); });
+                                         [](int i) { return xs_index<kXPerm>(i); });
 #pragma unroll
                             for (int r = 0; r < NVR; r++) ev[r] = C1::fix(ev28[r], ((tid + r * 1024) * 4) >> C1::LOG2C);
                         }
                     } else
                     rot_k28(p.x, p.x_su, p.x_hadk, p.x_pre, p.x_post, xs, reinterpret_cast<unsigned char *>(lut), wave, lane,
-                            [](int i) { return xs_index(i); }, [&] {
+                            [](int i) { return xs_index<kXPerm>(i); }, [&] {
 #pragma unroll
                                 for (int r = 0; r < NVR; r++) ev[r] = C1::entry(p.tab, ((tid + r * 1024) * 4) >> C1::LOG2C);
                             });
@@ -1249,7 +1255,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                     }
                     auto store_row = [&](uint16_t *dst) {
                         return [=](int, int, int i, float v) {
-                            dst[xs_index(i)] = __builtin_bit_cast(uint16_t, (_Float16)((float)(_Float16)(v * post) * p.x_post));
+                            dst[xs_index<kXPerm>(i)] = __builtin_bit_cast(uint16_t, (_Float16)((float)(_Float16)(v * post) * p.x_post));
                         };
                     };
                     if (p.x_rot == 4) wht64_wg_stage2<4>(wave, lane, p.x_pre, d1buf, store_row(xs));
@@ -1259,7 +1265,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                     for (int i = tid * 8; i < total + 32; i += NT * 8) {
                         u32x4 v{0u, 0u, 0u, 0u};
                         if (i < total) v = *reinterpret_cast<const u32x4 *>(p.x + i);
-                        xs_put(xs, i, v);
+                        xs_put<kXPerm>(xs, i, v);
                     }
                 }
                 cur_x = p.x;
@@ -1305,8 +1311,8 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                         using CL = decltype(cc);
                         auto &wk = reinterpret_cast<uint32_t(&)[CL::NW]>(w.a);
                         const uint32_t lo = (uint32_t)(lane & (CL::C - 1)) << 2;
-                        if (NBG == 1 && x_lds) gemv_run<CL, true, NBG>(wk, lut, lo, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-                        else gemv_run<CL, false, NBG>(wk, lut, lo, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                        if (NBG == 1 && x_lds) gemv_run<CL, kXL, NBG>(wk, lut, lo, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                        else gemv_run<CL, 0, NBG>(wk, lut, lo, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
                     });
             }
             if (!lut_job)
@@ -1315,24 +1321,24 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                 using CK = TcqCodec<C1::S_, KVr>;
                 auto &wk = reinterpret_cast<uint32_t(&)[KVr]>(w.a);
                 const StreamView &sv = on2 ? sv2 : sv1;
-                if (NBG == 1 && x_lds) gemv_run<CK, true, NBG>(wk, lut, laneoff, sv, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-                else gemv_run<CK, false, NBG>(wk, lut, laneoff, sv, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                if (NBG == 1 && x_lds) gemv_run<CK, kXL, NBG>(wk, lut, laneoff, sv, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else gemv_run<CK, 0, NBG>(wk, lut, laneoff, sv, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
             });
         } else
         if constexpr (NBG == 1) {
             if (x_lds) {
-                if constexpr (!TWO) gemv_run<C1, true, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-                else if (on2) gemv_run<CB, true, 1>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-                else gemv_run<C1, true, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                if constexpr (!TWO) gemv_run<C1, kXL, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else if (on2) gemv_run<CB, kXL, 1>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else gemv_run<C1, kXL, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
             } else {
-                if constexpr (!TWO) gemv_run<C1, false, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-                else if (on2) gemv_run<CB, false, 1>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-                else gemv_run<C1, false, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                if constexpr (!TWO) gemv_run<C1, 0, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else if (on2) gemv_run<CB, 0, 1>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else gemv_run<C1, 0, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
             }
         } else {
-            if constexpr (!TWO) gemv_run<C1, false, NBG>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-                else if (on2) gemv_run<CB, false, NBG>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-            else gemv_run<C1, false, NBG>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+            if constexpr (!TWO) gemv_run<C1, 0, NBG>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else if (on2) gemv_run<CB, 0, NBG>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+            else gemv_run<C1, 0, NBG>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
         }
         QPAL_STAMP(4);
 
