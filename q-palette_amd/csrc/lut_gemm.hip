@@ -8,11 +8,11 @@ int launch_lut_tc_gemm(const TcMultiParams &p, int bits, int vec, int nbg, int g
 #define QPAL_LUT(B_, V_)                                                                                                   \
     if (bits == B_ && vec == V_) {                                                                                         \
         using C = LutCodec<B_, V_>;                                                                                        \
-        if (nbg == 1) hipLaunchKernelGGL((tc_gemm_kernel<C, void, 1>), dim3(grid), dim3(64 * kGemmWaves), 0, stream, p);   \
-        else if (nbg == 2) hipLaunchKernelGGL((tc_gemm_kernel<C, void, 2>), dim3(grid), dim3(64 * kGemmWaves), 0, stream, p);   \
-        else if (nbg == 4) hipLaunchKernelGGL((tc_gemm_kernel<C, void, 4>), dim3(grid), dim3(64 * kGemmWaves), 0, stream, p); \
+        if (nbg == 1) hipLaunchKernelGGL((tc_gemm_kernel<C, void, 1>), dim3(grid), dim3(64 * kGemmWaves), 0, stream, gemm_item_table(p), p);   \
+        else if (nbg == 2) hipLaunchKernelGGL((tc_gemm_kernel<C, void, 2>), dim3(grid), dim3(64 * kGemmWaves), 0, stream, gemm_item_table(p), p);   \
+        else if (nbg == 4) hipLaunchKernelGGL((tc_gemm_kernel<C, void, 4>), dim3(grid), dim3(64 * kGemmWaves), 0, stream, gemm_item_table(p), p); \
         else if constexpr (C::LDS_DWORDS * 4 + 2 * 8 * kGemmXGroup <= 160 * 1024)                                          \
-            hipLaunchKernelGGL((tc_gemm_kernel<C, void, 8>), dim3(grid), dim3(64 * kGemmWaves), 0, stream, p);             \
+            hipLaunchKernelGGL((tc_gemm_kernel<C, void, 8>), dim3(grid), dim3(64 * kGemmWaves), 0, stream, gemm_item_table(p), p);             \
         else return QPAL_E_SHAPE;                                                                                          \
         return (int)hipGetLastError();                                                                                     \
     }

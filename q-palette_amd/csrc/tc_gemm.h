@@ -21,6 +21,17 @@ constexpr int kGemmWaves = 8;
 constexpr int kGemmXRow = 144;              // bytes per (batch row, column half) row of a step's x tile: 128 + 16 pad (bank spread)
 constexpr int kGemmXGroup = 16 * kGemmXRow;  // one batch group (8 rows x 2 column halves)
 
+// host: the packed item table of a launch (<= 4 jobs, boundaries < 1023), 0: none (the kernel scans the table)
+inline int gemm_item_table(const TcMultiParams &mp) {
+    if (mp.njobs < 2 || mp.njobs > 4) return 0;
+    int ie = 1 << 30;
+    for (int j = 0; j < 3; j++) {
+        const int end = j < mp.njobs - 1 ? mp.item_end[j] : 0x3ff;
+        ie |= (end < 0x3ff ? end : 0x3ff) << (10 * j);
+    }
+    return ie;
+}
+
 // geometry of one job (host: plan_gemm): items = ceil(nrows / 8) * sk, item -> (row group, K split)
 //   uses TcParams: nrows, nsc1/2, st1/2, col2, sk, out/ldo, wscale/oscale, accumulate, c1/c2, x, tab, n, k
 
@@ -145,7 +156,11 @@ __device__ __forceinline__ GemmStep gemm_where(const TcParams &p, int g) {
 }
 
 template <class C1, class C2, int NBG>
-__global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiParams mp) {
+// eie: the launch's item table packed into one PRELOADED dword (gemm_item_table; tc_kernels.h early_args does the same for the GEMV
+// kernels): a workgroup knows the job of its first item before the kernel-argument block has arrived and fetches THAT job's
+// parameters in the first scalar-load round trip (every workgroup used to scan the table after one round trip and fetch its job
+// in a second, dependent one)
+__global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const int eie, const TcMultiParams mp) {
     constexpr bool TWO = !std::is_void_v<C2>;
     using CB = std::conditional_t<TWO, C2, C1>;
     constexpr int W = kGemmWaves, NT = 64 * W;
@@ -169,8 +184,19 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const TcMultiP
 #pragma unroll
     for (int i = 0; i < kMaxJobs; i++) ie[i] = mp.item_end[i];
     const int total_items = ie[kMaxJobs - 1];
-    int cur_j = -1;
-    TcParams p;
+    int jf = 0;
+    if (eie != 0) {
+        const int b = (int)blockIdx.x, e0 = eie & 0x3ff, e1 = (eie >> 10) & 0x3ff, e2 = (eie >> 20) & 0x3ff;
+        if (b >= e0) {
+            jf = 1;
+            if (b >= e1) {
+                jf = 2;
+                if (b >= e2) jf = 3;
+            }
+        }
+    }
+    int cur_j = jf;
+    TcParams p = mp.job[jf];
 
     for (int gitem = blockIdx.x; gitem < total_items; gitem += gridDim.x) {
         int j = 0, item_begin = 0;
