@@ -252,8 +252,11 @@ void plan_gemm(TcMultiParams &mp, int &grid, bool two_per_cu = false) {
             const int T = p.st1 + p.st2;
             int sk = 1;
             while (groups * sk < want_items && T / (sk * 2) >= min_steps && sk < 32) sk *= 2;
-            if (force_sk > 0) sk = force_sk;
-            if (sk > T) sk = T;
+            if (force_sk > 0) {  // (a power of two: the kernel shifts)
+                sk = 1;
+                while (sk * 2 <= force_sk) sk *= 2;
+            }
+            while (sk > 1 && sk > T) sk >>= 1;
             p.sk = sk;
             p.nitems = ((p.nrows + kGemmWaves - 1) / kGemmWaves) * sk;
             total += p.nitems;
