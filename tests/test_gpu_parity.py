@@ -774,3 +774,19 @@ def test_pair_mode_rows_shared_by_two_workgroups(qp, oracle, qstr, m, k):
         assert r.returncode == 0, r.stderr[-1500:]
         lines = [l for l in r.stderr.splitlines() if l.startswith("[qpal plan]")]
         assert lines and (" pair " in lines[-1]) == want, lines
+
+
+def test_lane_xor_forms_match_the_shuffle(tmp_path):
+    """qpal_common.h lane_xor<MASK> / group_sum / wave_sum / wave_max (DPP quad_perm, row mirrors, gfx950 permlane swaps: what the
+    epilogues and the glue kernels' reductions use instead of __shfl_xor's LDS permute) agree with __shfl_xor lane for lane:
+    perf/lane_xor_test.hip, compiled here with hipcc and run on the GPU."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "lane_xor_test.bin")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-I", os.path.join(root, "include"),
+                    "-I", os.path.join(root, "q-palette_amd", "csrc"), os.path.join(root, "perf", "lane_xor_test.hip"), "-o", exe],
+                   check=True, capture_output=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "MISMATCH" not in r.stdout, r.stdout + r.stderr
