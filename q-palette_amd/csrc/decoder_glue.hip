@@ -132,12 +132,21 @@ struct AttnRopeParams {
     int nq, nkv;
     long max_len;
     float scale;
+    int log2_rep;                  // log2(nq / nkv) when that is a power of two (host), else -1: kv head of a q head without a division
 };
 
 // What a thread of the one-head body reads from global memory that does NOT depend on the position: its element of inv_freq and of
 // the new q / k (or v) row, and its first round of cache rows for the score and the value loops (rows past `pos` are masked later;
 // any row below max_len is readable).  Round 4: requested at the top of the kernel, BEFORE *pos is waited for — the body was a
 // chain of five dependent round trips (arguments -> *pos -> inv_freq -> q / k -> cache rows), ~2 of its 5.6 us.
+__device__ __forceinline__ int attn_kv_head(const AttnRopeParams &p, int head) {
+    return p.log2_rep >= 0 ? head >> p.log2_rep : head / (p.nq / p.nkv);
+}
+// the q head that writes its kv head's new cache row: the first of the group
+__device__ __forceinline__ bool attn_first_of_group(const AttnRopeParams &p, int head) {
+    return p.log2_rep >= 0 ? (head & ((1 << p.log2_rep) - 1)) == 0 : head % (p.nq / p.nkv) == 0;
+}
+
 template <int HD>
 struct AttnPre {
     uint32_t inv, x1, x2;   // fp32 bit patterns
@@ -149,7 +158,7 @@ struct AttnPre {
 template <int HD, int NW>
 __device__ __forceinline__ void attn_prefetch(const AttnRopeParams &p, const int head, AttnPre<HD> &pre) {
     constexpr int HALF = HD / 2, LPR = HD / 8, RPW = 64 / LPR, DPL = HD / 64;
-    const int rep = p.nq / p.nkv, kh = head / rep;
+    const int kh = attn_kv_head(p, head);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint16_t *K = p.kcache + (long)kh * p.max_len * HD, *V = p.vcache + (long)kh * p.max_len * HD;
     {
@@ -209,7 +218,7 @@ __device__ __forceinline__ void attn_rope_head(const AttnRopeParams &p, float *s
     // sh: scores [cap] | q, new k (fp16 bits) [HD/2 dwords each] | new v [HD] | partial out [NW][HD] | reduce [2 NW]
     float *sc = sh, *vn = sh + cap + 2 * HALF, *po = vn + HD, *red = po + NW * HD;
     uint32_t *qh = reinterpret_cast<uint32_t *>(sh + cap), *knh = qh + HALF;
-    const int rep = p.nq / p.nkv, kh = head / rep;
+    const int kh = attn_kv_head(p, head);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const gptr<const uint16_t> K = as_global(p.kcache) + (long)kh * p.max_len * HD, V = as_global(p.vcache) + (long)kh * p.max_len * HD;
 
@@ -232,7 +241,7 @@ __device__ __forceinline__ void attn_rope_head(const AttnRopeParams &p, float *s
             uint16_t *dst16 = reinterpret_cast<uint16_t *>(is_k ? knh : qh);
             dst16[i] = __builtin_bit_cast(uint16_t, o1);
             dst16[i + HALF] = __builtin_bit_cast(uint16_t, o2);
-            if (is_k && head % rep == 0 && ok) {
+            if (is_k && attn_first_of_group(p, head) && ok) {
                 uint16_t *dst = p.kcache + ((long)kh * p.max_len + pos) * HD;
                 dst[i] = __builtin_bit_cast(uint16_t, o1);
                 dst[i + HALF] = __builtin_bit_cast(uint16_t, o2);
@@ -244,7 +253,7 @@ __device__ __forceinline__ void attn_rope_head(const AttnRopeParams &p, float *s
             else fv = p.v[(long)kh * HD + d];
             const _Float16 hv = (_Float16)fv;
             vn[d] = (float)hv;
-            if (head % rep == 0 && ok) p.vcache[((long)kh * p.max_len + pos) * HD + d] = __builtin_bit_cast(uint16_t, hv);
+            if (attn_first_of_group(p, head) && ok) p.vcache[((long)kh * p.max_len + pos) * HD + d] = __builtin_bit_cast(uint16_t, hv);
         }
     }
     __syncthreads();
@@ -433,10 +442,11 @@ __global__ __launch_bounds__(64 * NW) void attn_rope_split_kernel(const AttnSpli
     // the LDS score buffer was sized for): a 500-position context in a 32 k cache still spreads over 8 chunks per kv head
     // instead of sitting in one.  Chunks 0 .. neff-1 hold positions <= pos (the last of them the new one); the workgroups of
     // the others leave at once and take no ticket.
-    long cld = ((pos + sp.nsplit) / sp.nsplit + 63) / 64 * 64;
+    // (32-bit unsigned: positions are below max_len < 2^31 — the 64-bit divisions that stood here were ~400 instructions)
+    long cld = (long)((((unsigned)pos + (unsigned)sp.nsplit) / (unsigned)sp.nsplit + 63u) & ~63u);
     if (cld > CL) cld = CL;
     const long c0 = (long)split * cld;
-    const int neff = (int)(pos / cld) + 1;
+    const int neff = (int)((unsigned)pos / (unsigned)cld) + 1;
     if (split >= neff) return;
     const bool owner = split == neff - 1;                    // this chunk holds the new position
     const long cend = pos < c0 + cld ? pos : c0 + cld;       // cached positions of the chunk: [c0, cend)
@@ -894,11 +904,15 @@ extern "C" int qpal_attn_rope_decode(const float *q, const float *k, const float
                                      const long *pos, const float *inv_freq, int nq, int nkv, int hd, long max_len, float scale,
                                      void *ws, long ws_bytes, void *stream) {
     if (!q || !k || !v || !kcache_f16 || !vcache_f16 || !out_f16 || !pos || !inv_freq) return QPAL_E_NULL;
-    if (nq < 1 || nkv < 1 || nq % nkv || max_len < 1 || (hd != 64 && hd != 128 && hd != 256)) return QPAL_E_SHAPE;
+    if (nq < 1 || nkv < 1 || nq % nkv || max_len < 1 || max_len >= (1L << 30) || (hd != 64 && hd != 128 && hd != 256)) return QPAL_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(kcache_f16) | reinterpret_cast<uintptr_t>(vcache_f16)) & 15) return QPAL_E_ALIGN;
     if (max_len % 4) return QPAL_E_ALIGN;  // the fp16 q block behind the scores is read with 16-byte LDS loads
     AttnRopeParams p{q, k, v, static_cast<uint16_t *>(kcache_f16), static_cast<uint16_t *>(vcache_f16),
-                     static_cast<uint16_t *>(out_f16), pos, inv_freq, nq, nkv, max_len, scale};
+                     static_cast<uint16_t *>(out_f16), pos, inv_freq, nq, nkv, max_len, scale, -1};
+    {
+        const int rep_ = nq / nkv;
+        if (rep_ > 0 && (rep_ & (rep_ - 1)) == 0) p.log2_rep = __builtin_ctz((unsigned)rep_);
+    }
     int ns, ch, nw;
     size_t slds, wsb;
     attn_split_geometry(nq, nkv, hd, max_len, ns, ch, nw, slds, wsb);
