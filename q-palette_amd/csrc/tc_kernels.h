@@ -1364,22 +1364,33 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                 });
             });
         }
+        // (what the final sum needs besides the partials — row, scale, destination — is worked out in FRONT of the barrier: behind it
+        // only the reducing wave runs, and everything there is the launch's tail)
+        const int fr = tid & 31, frl = tid >> 5;
+        const bool fin = tid < (32 << log2_rpw);
+        const int fsrow = fin ? row_of(frl) : 0;
+        float fosc = (fin && p.wscale) ? p.oscale * (float)__builtin_bit_cast(_Float16, (uint16_t)wraw) : p.oscale;
+        int fdoff = fsrow * 32 + fr;                          // (offsets, not pointers: a pointer through an asm loses its address space)
+        int froff = (frl << p.log2_wpr) * p.n * 32 + fr;
+        asm volatile("" : "+v"(fosc), "+v"(fdoff), "+v"(froff));
+        float *fdst = p.out + fdoff;
+        const float *fred = red + froff;
         QPAL_STAMP(5);
         __syncthreads();
         QPAL_STAMP(6);
-        if (tid < (32 << log2_rpw)) {
-            const int r = tid & 31, rl = tid >> 5;
-            const int srow = row_of(rl);
+        if (fin) {
+            const int r = fr, rl = frl;
+            const int srow = fsrow;
             [[maybe_unused]] bool continue_item = false;
             if (srow < p.nrows) {
                 // the incoherent wrappers' `* Wscale * scale`, fused
-                const float osc = p.wscale ? p.oscale * (float)__builtin_bit_cast(_Float16, (uint16_t)wraw) : p.oscale;
+                const float osc = fosc;
                 if constexpr (ROT == 1) {
                     if (p.act_out) {  // SwiGLU of an interleaved up | gate layer: threads (rl, r) and (rl + 1, r) are lanes r, r + 32
                         float v = 0.f;
                         for (int qq = 0; qq < wpr; qq++) v += red[((rl << p.log2_wpr) + qq) * 32 + r];
                         const float mine = (float)(_Float16)(v * osc);           // the reference's fp16 up / gate
-                        const float gate = __shfl_down(mine, 32, 64);
+                        const float gate = lane_xor<32>(mine);  // (lanes r < 32 read lane r + 32: a permlane swap, not an LDS permute)
                         if ((rl & 1) == 0) {
                             const float sg = (float)(_Float16)(gate * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gate * -1.44269504f)));
                             uint16_t av = __builtin_bit_cast(uint16_t, (_Float16)(sg * mine));
@@ -1392,8 +1403,8 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                 if (!continue_item)
                 for (int b = 0; b < p.n; b++) {
                     float v = 0.f;
-                    for (int qq = 0; qq < wpr; qq++) v += red[(((rl << p.log2_wpr) + qq) * p.n + b) * 32 + r];
-                    float *dst = p.out + (long)b * p.ldo + (long)srow * 32 + r;
+                    for (int qq = 0; qq < wpr; qq++) v += fred[(qq * p.n + b) * 32];
+                    float *dst = fdst + (long)b * p.ldo;
                     v *= osc;
                     if (p.sk > 1 || (PAIRK && p.sk < 0 && rl >= wholes)) atomicAdd(dst, v);
                     else if (p.accumulate) *dst += v;  // the residual add of a decoder block: out is the fp32 residual stream
