@@ -62,13 +62,10 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--streams", type=int, default=1,
                     help="1: every GEMV on one stream; 3: q|k|v and gate|up fork onto side streams inside the graph")
-    ap.add_argument("--launch", default="multi", choices=["single", "multi", "chain"],
+    ap.add_argument("--launch", default="multi", choices=["single", "multi"],
                     help="single: one launch per linear (7/layer); multi (default, the fastest measured): q|k|v and gate|up "
                          "(projections of one input) go out as one multi-job launch each (4 launches/layer, same arithmetic, "
-                         "same buffers); chain: the same multi-job GEMVs as PHASES of one persistent launch per run of equal "
-                         "codecs — stream order between phases kept by an in-kernel arrival counter (csrc/tc_chain.h; measured "
-                         "10-15 %% slower than multi: DESIGN.md §4.6); phases no chain can take (SIMT packing, mixed codecs in "
-                         "one phase, batch > 8) run as multi-job launches")
+                         "same buffers)")
     ap.add_argument("--distinct-codebooks", action="store_true",
                     help="give every linear its own random codebook (default: one codebook per model, as in real "
                          "Q-Palette checkpoints where every layer stores a copy of the same k-means codebook)")
@@ -245,43 +242,17 @@ KINDS = ["q|k|v", "o", "gate|up", "down"]  # the four dependent multi-job launch
 
 def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=False, gather=None, side=(), main_stream=None,
                only_kind=None):
-    """-> (token, parts): token() runs every quantized linear of `layers` once (one decoded token at batch n, plain inputs
-    xs[in_features]) and returns the outputs in model order; parts: the chain / multi-job partition of --launch chain, else
-    None.  Also what tests/test_bench_workloads.py drives for the published mixed-scheme workloads.
+    """-> (token, None): token() runs every quantized linear of `layers` once (one decoded token at batch n, plain inputs
+    xs[in_features]) and returns the outputs in model order.  Also what tests/test_bench_workloads.py drives for the published
+    mixed-scheme workloads.
     only_kind (multi-job launches only): run just launch kind 0..3 of every block, with exactly the arguments it has inside
     the token (timing of one launch kind; o / down then accumulate into whatever their pre-zeroed buffer holds)."""
-    parts = None  # --launch chain: GemvChain objects (one launch each) and left-over Phases (multi-job launches)
-    if launch == "chain" and gather is None:
-        Phase = qp.chain.Phase
-        plan = []
-        for groups in layers:
-            pre = {}
-            for gi, grp in enumerate(groups):
-                ph = Phase(layers=[m for m, _, _ in grp], x=xs[grp[0][1]])
-                if gi in (0, 2) and not no_prezero and len(groups[gi + 1]) == 1:
-                    pre[gi + 1] = torch.empty((n, groups[gi + 1][0][0].out_features), dtype=torch.float32, device=device)
-                    ph.prezero = pre[gi + 1]
-                elif gi in pre:
-                    ph.outs, ph.outs_zeroed = [pre[gi]], True
-                plan.append(ph)
-        parts = qp.chain.build_chains(plan, n, device)
-
-    def token_chain():
-        outs = []
-        for part in parts:
-            if isinstance(part, qp.chain.GemvChain):
-                part.launch()
-                outs += [y for ph in part.phases for y in ph.results]
-            else:
-                outs += qp.multi_gemv(part.layers, part.x, outs=part.outs, outs_zeroed=part.outs_zeroed, prezero=part.prezero)
-        return outs
-
     # Batched token (4 <= n <= fused batch, multi-job launches): the lockstep GEMM kernel splits K of every launch kind, so every
     # output must start at zero.  The harness owns the buffers, as a decode loop would: the outputs of a launch are consecutive
     # blocks of one allocation, zeroed by the launch BEFORE it (prezero) — one memset node per token instead of five per layer.
     # Up to max_chunked_batch the batch goes through each launch kind in passes of <= 64 rows (the second pass re-reads weights the
     # first has just pulled through L2 / the Infinity Cache).
-    batched = (gather is None and launch in ("multi", "chain") and parts is None and only_kind is None
+    batched = (gather is None and launch == "multi" and only_kind is None
                and n >= int(os.environ.get("QPAL_GEMM_MIN_BATCH", "4"))
                and all(n <= max(m.max_fused_batch, m.max_chunked_batch) and type(m) in qp.linear._PACKED_KEYS
                        for groups in layers for grp in groups for m, _, _ in grp))
@@ -324,7 +295,7 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
     # (Round 4: per GROUP — a mixed-scheme model's groups of tensor-core-order layers get owned, pre-zeroed outputs although other
     # groups of the model are SIMT-packed: their single-codec gate | up launches then pair like the uniform model's.)
     owned = None
-    if launch in ("multi", "chain") and parts is None and not batched and not no_prezero and \
+    if launch == "multi" and not batched and not no_prezero and \
             all(n <= m.max_fused_batch for groups in layers for grp in groups for m, _, _ in grp):
         owned = []
         for groups in layers:
@@ -345,8 +316,6 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
             owned = None
 
     def token():
-        if parts is not None:
-            return token_chain()
         if batched:
             return token_batched()
         outs = []
@@ -376,7 +345,7 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
                     continue
                 x = xs[grp[0][1]]
                 mods = [m for m, _, _ in grp]
-                if gather is not None and launch in ("multi", "chain") and n <= min(m.max_fused_batch for m in mods):
+                if gather is not None and launch == "multi" and n <= min(m.max_fused_batch for m in mods):
                     # row-sharded model (--parallel tp): the same multi-job launches on every rank's shard; the outputs of
                     # o_proj / down_proj feed full-width consumers (the next block's rotation): all-gather them.  q|k|v stay
                     # head-sharded through attention, gate|up channel-sharded into down_proj's rotation input, which is
@@ -390,7 +359,7 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
                     if only_kind is None or only_kind == gi:
                         outs += qp.multi_gemv(mods, x)   # passes of the fused launches up to max_chunked_batch, decode + GEMM above
                     continue
-                if launch in ("multi", "chain") and gather is None:
+                if launch == "multi" and gather is None:
                     # projections of one input: one multi-job launch per codec.  The attention-input / mlp-input
                     # launches also zero the output of o_proj / down_proj, so that a split-K there (few rows:
                     # half of the CUs would idle) needs no memset node of its own.
@@ -431,7 +400,7 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
                     outs.append(y)
         return outs
 
-    return token, parts
+    return token, None
 
 
 def algorithmic_bytes(qp, layers, batch):
@@ -716,7 +685,7 @@ def main():
     inc = []
 
     def build_incoherent_state():
-        assert args.launch in ("multi", "chain") and gather is None, "--incoherent runs on the multi-job launch path"
+        assert args.launch == "multi" and gather is None, "--incoherent runs on the multi-job launch path"
         gen = torch.Generator(device=device).manual_seed(4321)
         for groups in layers:
             per = []
@@ -893,7 +862,7 @@ def main():
     # Second figure (N = 1 only, after the timed region of the headline): the same token with every projection group
     # inside the reference's incoherence wrapper (rotation + scales), i.e. what an IncoherentMLP / attention forward costs.
     extra = None
-    if world == 1 and not args.incoherent and not args.no_incoherent_extra and args.launch in ("multi", "chain") and graph is not None:
+    if world == 1 and not args.incoherent and not args.no_incoherent_extra and args.launch == "multi" and graph is not None:
         try:
             build_incoherent_state()
             with torch.cuda.stream(main_stream):
@@ -926,15 +895,11 @@ def main():
     tokens = args.steps * n * (1 if tp else world)
     value = tokens / wall
     nlinear = sum(len(grp) for groups in layers for grp in groups)
-    multi = args.launch in ("multi", "chain") and not tp
+    multi = args.launch == "multi" and not tp
     mixed_kv = n <= 8 and not args.incoherent
     nphase = sum(len(qp.linear.launch_groups([m for m, _, _ in grp], mixed_kv=mixed_kv)) if multi else len(grp)
                  for groups in layers for grp in groups)  # dependent multi-job GEMVs per token
     nlaunch = nphase  # GEMV kernel launches per token
-    if parts is not None:
-        nlaunch = sum(1 if isinstance(p_, qp.chain.GemvChain) else len(qp.linear.launch_groups(p_.layers, mixed_kv=mixed_kv))
-                      for p_ in parts)
-        assert qp.chain.chain_error(device) == 0, "a chain launch gave up waiting for a dependency"
     abytes = algorithmic_bytes(qp, layers, n) * (world if tp else 1)  # per token
     t_token = dev_s / args.steps
     achieved = abytes / (world if tp else 1) / t_token / 1e9  # per GPU
@@ -960,8 +925,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
                      "traffic_source": traffic_source(),
-                     "kernel": ("qpal::tc_chain_kernel (persistent: every GEMV phase of a token)" if parts is not None
-                                else "qpal::tc_gemv_kernel (every GEMV launch of a token)"),
+                     "kernel": "qpal::tc_gemv_kernel (every GEMV launch of a token)",
                      "algorithmic_bytes_per_launch": abytes / (world if tp else 1) / nlaunch,
                      "avg_launch_us": t_token / nlaunch * 1e6,
                      "avg_phase_us": t_token / nphase * 1e6},

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define QPAL_VERSION 230
+#define QPAL_VERSION 300
 
 #define QPAL_OK 0
 #define QPAL_E_SHAPE (-1)   /* m, k, n outside the supported set (m%32, k%32, 1<=n<=64 ...) */
@@ -78,14 +78,8 @@ typedef struct qpal_tcq_job {
     int kv;            /* 0: the call's KV1.  Otherwise this job's own KV (split NONE only): jobs of one S but different
                           bit widths — q, k, v of a mixed-scheme model — then share ONE launch and one codebook image
                           (KV 2..8 for S = 9, 8..10 for S = 10, 9..10 for S = 11; batch <= 8; no x_had) */
-    /* chain launches (qpal_*_chain_build below; the per-launch entry points take x_f32 only together with x_had, see the
-     * decoder-block fusion fields, and ignore the two flags): */
-    const void *x_f32; /* fp32 [n][k] or NULL: the input is fp16(x_f32[i] * x_f32_scale), x_f32 being the fp32 output of an
-                          EARLIER phase of the same chain (x may then be NULL) */
-    float x_f32_scale; /* 0 is read as 1 */
-    int x_fresh;       /* 1: x (fp16) is written by an earlier phase of the same chain */
-    int publish;       /* 1: out is read (as x_f32) by a later phase of the same chain */
-    /* decoder-block fusion (per-launch entry points, x_had jobs): the rotation reads the fp32 residual stream and applies
+    const void *x_f32; /* fp32 [k] or NULL (see below: only together with x_had) */
+    /* decoder-block fusion (x_had jobs): the rotation reads the fp32 residual stream and applies
      * the RMSNorm in front of it (lib/linear/incoherent_linear.py:76-108 is called on `input_layernorm(h)` by the model,
      * model/llama.py), and o_proj / down_proj add their result to it.  With x_had = 1: x_f32 (fp32 [k], 16-byte aligned) may
      * replace x; x_rms_eps > 0 normalises x <- x * rsqrt(mean(x^2) + eps) * x_rms_w (fp16 [k] or NULL) in fp32 before the
@@ -143,9 +137,6 @@ typedef struct qpal_lut_job {
     float x_post;
     const void *x_su;
     const void *x_f32;    /* as in qpal_tcq_job */
-    float x_f32_scale;
-    int x_fresh;
-    int publish;
     float x_rms_eps;      /* as in qpal_tcq_job */
     const void *x_rms_w;
     int accumulate;
@@ -156,46 +147,6 @@ typedef struct qpal_lut_job {
 } qpal_lut_job;
 int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits, int vec, void *prezero,
                            long prezero_bytes, void *stream);
-
-/* Jobs of DIFFERENT FAMILIES in one launch: TCQ layers of codebook size S (every job carries its own kv, column-split layers
- * also kv2: see qpal_tcq_job) next to VQ/SQ layers in tensor-core packing (lut_bits[i], lut_vec[i] for lut_jobs[i]) whose
- * codebook image is no larger than the TCQ one: vec 2 with 2..8 bits, vec 1 with 2, 3, 4, 7, 8 bits.  What q | k | v of a
- * mixed-scheme model (the reference's MSQ results give every projection its own quantizer) need to stay ONE launch.  Outputs,
- * epilogue fields, ldo, out_zeroed and prezero as in the single-family calls; n <= 8; no fused rotation (x_had = 0).
- * ntcq may be 0 (VQ/SQ layers of different codecs); nlut >= 1; ntcq + nlut <= 8.                                          */
-int qpal_mixed_gemv_multi(const qpal_tcq_job *tcq_jobs, int ntcq, const qpal_lut_job *lut_jobs, int nlut, const int *lut_bits,
-                          const int *lut_vec, int n, int S, void *prezero, long prezero_bytes, void *stream);
-
-/* Chains: a sequence of DEPENDENT multi-job GEMV launches of ONE codec and batch (phase p+1 may consume what phase p
- * wrote) executed by ONE persistent launch — q|k|v -> o -> gate|up -> down -> the next block's q|k|v ... of a decoded
- * token.  Stream order between the phases is kept by an in-kernel arrival counter; what does not depend on the
- * activations (codebook image, the first weight steps and their decode) runs ahead of it.  No counterpart in the
- * reference (kernels/tcq-kernels/src/inference.cu:1826-1860: one cold launch per linear); exists because at batch 1 a
- * kernel boundary + cold prologue + tail cost more than the 2-48 MB GEMVs themselves.
- *   build   (host, no GPU call) turns the phases into a launch plan ("blob", host memory, qpal_chain_blob_bytes(nphases)
- *           bytes); the caller copies the blob to device memory it owns (16-byte aligned) and keeps both copies.
- *           ncu = compute units of the device (hipDeviceProp multiProcessorCount): the launch uses one workgroup per CU
- *           and needs all of them resident.  Limits: batch <= 8, no x_had, no per-job kv, split NONE or COLS, every phase
- *           must fit one round (m / 32 / 8 <= ncu row groups): QPAL_E_SHAPE / QPAL_E_PARAM otherwise — use the per-launch
- *           entry points for those.  A split-K job needs out_zeroed = 1 (e.g. the prezero of an earlier phase).
- *   launch  one kernel on `stream`.  dev_ws: QPAL_CHAIN_WS_BYTES of device memory, 128-byte aligned, zero-filled ONCE by
- *           the caller and then left alone (shared by all chains launched on one stream; graph replay needs no reset).
- *           After a synchronisation, word 65 of dev_ws != 0 means a dependency wait gave up (never observed; guards
- *           against a hang if a workgroup could not become resident).                                                */
-#define QPAL_CHAIN_WS_BYTES 2048
-typedef struct qpal_chain_phase {
-    const qpal_tcq_job *tcq_jobs;  /* qpal_tcq_chain_build: njobs jobs sharing one input */
-    const qpal_lut_job *lut_jobs;  /* qpal_lut_chain_build */
-    int njobs;                     /* 1..8 */
-    void *prezero;                 /* as in qpal_tcq_gemv_multi: zero-filled by this phase for a LATER phase */
-    long prezero_bytes;
-} qpal_chain_phase;
-long qpal_chain_blob_bytes(int nphases);
-int qpal_tcq_chain_build(void *host_blob, long blob_bytes, const qpal_chain_phase *phases, int nphases, int n,
-                         int S, int KV1, int KV2, int split, int ncu);
-int qpal_lut_chain_build(void *host_blob, long blob_bytes, const qpal_chain_phase *phases, int nphases, int n,
-                         int bits, int vec, int ncu);
-int qpal_chain_launch(const void *dev_blob, const void *host_blob, void *dev_ws, void *dbg /* NULL */, void *stream);
 
 /* Same format decoded to fp16 W[m][k].  Replaces decompress_ptr, vq-tensor inference.cu:1182-1226. */
 int qpal_lut_tc_dequant(void *out_f16, const void *qweight, const void *lut,

@@ -15,7 +15,6 @@ for w in llama3.1-8b_mem3p25 llama3.1-8b_figure1c llama3.1-8b_figure1d llama3.1-
   timeout -k 10 300 $B --workload $w 2>/dev/null | line "$w multi" >> $out/workloads.txt
 done
 timeout -k 10 300 $B --workload llama3.1-8b_figure1c --packing mi355x 2>/dev/null | line "llama3.1-8b_figure1c multi packing=mi355x" >> $out/workloads.txt
-timeout -k 10 300 $B --launch chain 2>/dev/null | line "llama3.1-8b_tcomb_6_7 chain" >> $out/workloads.txt
 timeout -k 10 300 $B --launch single 2>/dev/null | line "llama3.1-8b_tcomb_6_7 single" >> $out/workloads.txt
 for n in 8 16 17 32 64 65 128 129 256; do timeout -k 10 300 $B --batch $n 2>/dev/null | line "llama3.1-8b_tcomb_6_7 batch $n" >> $out/workloads.txt; done
 echo "workloads done"; cat $out/workloads.txt

@@ -19,5 +19,4 @@ done
 rm -rf $out/p1 $out/p2 $out/kt
 cd $GRAFT_REPO_ROOT
 QPAL_LIB=q-palette_amd/libqpal_hip_stamps.so python3 bench.py --steps 2 --warmup 1 --layers 2 --no-graph --no-cpu-baseline --no-incoherent-extra --no-kind-breakdown --no-whole-model 2>/dev/null | grep "^\[stamps\]" > $out/inkernel_stamps.txt
-QPAL_CHAIN_WAVES=16 python3 perf/chain_stamps.py > $out/chain_stamps.txt 2>/dev/null
 ls -la $out

@@ -11,7 +11,6 @@ Layout:
   linear/incoherent_linear.py  IncoherentLinear / IncoherentMLP / IncoherentSdpaAttention (lib/linear/incoherent_linear.py)
   packers.py       pack_trellis / pack_qweight / pack_qweight_{sq,vq}_simt on the C-ABI's host-side encoders
   shard.py         row-sharding of packed layers across GPUs (torch.distributed / RCCL)
-  chain.py         persistent chain launches: a sequence of dependent GEMV phases in ONE kernel (csrc/tc_chain.h)
 
 There is deliberately no CPU implementation here: the CPU restatement lives in /oracle and is test
 infrastructure only.
@@ -22,7 +21,6 @@ from . import mem_op  # noqa: F401
 from . import shard  # noqa: F401
 from . import hadamard  # noqa: F401
 from . import packers  # noqa: F401
-from . import chain  # noqa: F401
 from .linear import (  # noqa: F401
     IncoherentLinear,
     IncoherentMLP,

@@ -20,7 +20,7 @@ class TcqJob(ctypes.Structure):
     _fields_ = [("out", _P), ("c1", _P), ("c2", _P), ("x", _P), ("tlut", _P), ("m", _I), ("k", _I),
                 ("out_zeroed", _I), ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long),
                 ("x_had", _I), ("x_post", _F), ("x_su", _P), ("kv", _I),
-                ("x_f32", _P), ("x_f32_scale", _F), ("x_fresh", _I), ("publish", _I),
+                ("x_f32", _P),
                 ("x_rms_eps", _F), ("x_rms_w", _P), ("accumulate", _I), ("kv2", _I), ("act_out", _P), ("x_hadk", _P), ("x_K", _I), ("act_su", _P)]
 
 
@@ -28,17 +28,10 @@ class LutJob(ctypes.Structure):
     """qpal_lut_job (include/qpal.h)"""
     _fields_ = [("out", _P), ("qweight", _P), ("x", _P), ("lut", _P), ("m", _I), ("k", _I), ("out_zeroed", _I),
                 ("wscale", _P), ("oscale", _F), ("ldo", ctypes.c_long), ("x_had", _I), ("x_post", _F), ("x_su", _P),
-                ("x_f32", _P), ("x_f32_scale", _F), ("x_fresh", _I), ("publish", _I),
+                ("x_f32", _P),
                 ("x_rms_eps", _F), ("x_rms_w", _P), ("accumulate", _I), ("act_out", _P), ("x_hadk", _P), ("x_K", _I), ("act_su", _P)]
 
 
-class ChainPhase(ctypes.Structure):
-    """qpal_chain_phase (include/qpal.h)"""
-    _fields_ = [("tcq_jobs", ctypes.POINTER(TcqJob)), ("lut_jobs", ctypes.POINTER(LutJob)), ("njobs", _I),
-                ("prezero", _P), ("prezero_bytes", ctypes.c_long)]
-
-
-CHAIN_WS_BYTES = 2048
 PEER_WS_BYTES_PER_SLOT = 256
 IPC_HANDLE_BYTES = 64
 
@@ -46,8 +39,6 @@ IPC_HANDLE_BYTES = 64
 _SIGNATURES = {
     "qpal_tcq_gemv_multi": [ctypes.POINTER(TcqJob), _I, _I, _I, _I, _I, _I, _P, ctypes.c_long, _P],
     "qpal_lut_tc_gemv_multi": [ctypes.POINTER(LutJob), _I, _I, _I, _I, _P, ctypes.c_long, _P],
-    "qpal_mixed_gemv_multi": [ctypes.POINTER(TcqJob), _I, ctypes.POINTER(LutJob), _I, ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _I, _P,
-                              ctypes.c_long, _P],
     "qpal_tcq_gemv": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "qpal_tcq_dequant": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "qpal_lut_tc_gemv": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -63,9 +54,6 @@ _SIGNATURES = {
     "qpal_pack_lut_simt": [_P, _P, _I, _I, _I, _I],
     "qpal_hadamard": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "qpal_hadamard_rms": [_P, _P, _P, _F, _P, _P, _I, _I, _I, _F, _P],
-    "qpal_tcq_chain_build": [_P, ctypes.c_long, ctypes.POINTER(ChainPhase), _I, _I, _I, _I, _I, _I, _I],
-    "qpal_lut_chain_build": [_P, ctypes.c_long, ctypes.POINTER(ChainPhase), _I, _I, _I, _I, _I],
-    "qpal_chain_launch": [_P, _P, _P, _P, _P],
     "qpal_rope_kv": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_long, _P],
     "qpal_attn_decode": [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_long, _F, _P],
     "qpal_attn_rope_decode": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_long, _F, _P, ctypes.c_long, _P],
@@ -109,8 +97,6 @@ def lib():
         l.qpal_error_string.argtypes = [_I]
         l.qpal_error_string.restype = ctypes.c_char_p
         l.qpal_version.restype = _I
-        l.qpal_chain_blob_bytes.argtypes = [_I]
-        l.qpal_chain_blob_bytes.restype = ctypes.c_long
         l.qpal_attn_ws_bytes.restype = ctypes.c_long
         l.qpal_lm_head_ws_bytes.restype = ctypes.c_long
         _lib = l
@@ -124,4 +110,4 @@ def check(rc, what):
 
 
 def exported_symbols():
-    return list(_SIGNATURES) + ["qpal_error_string", "qpal_version", "qpal_chain_blob_bytes"]
+    return list(_SIGNATURES) + ["qpal_error_string", "qpal_version"]

@@ -7,7 +7,6 @@
 
 #include "lut_kernels_api.h"
 #include "tcq_kernels_api.h"
-#include "chain_api.h"
 #include "tc_gemm.h"
 #include <string.h>
 
@@ -326,52 +325,6 @@ bool use_gemm(int nbg, const TcMultiParams &mp) {
     return true;
 }
 
-// Geometry of one phase of a chain launch (tc_chain.h): 8 waves per workgroup, every workgroup owns at most ONE item
-// (grid = ncu workgroups, all resident).  Split-K only into outputs the caller guarantees zeroed (an earlier phase's
-// prezero): a chain cannot insert a memset between its phases.  false: the phase does not fit one round.
-bool plan_chain_phase(TcMultiParams &mp, const int *out_zeroed, int ncu) {
-    constexpr int W = kChainWaves;
-    int min_st = 1 << 30;
-    bool two = false;
-    for (int j = 0; j < mp.njobs; j++) {
-        const int st = mp.job[j].st1 + mp.job[j].st2;
-        if (st < min_st) min_st = st;
-        two = two || mp.job[j].st2 > 0;
-    }
-    constexpr int kMinSteps = kChainG > 1 ? kChainG : 1;  // the kernel's decode-ahead depth: a shorter chunk leaves slots dead
-    int log2_wpr = kChainLog2W;
-    while (log2_wpr > 0 && items_at(mp, log2_wpr, W) > ncu) log2_wpr--;
-    while (log2_wpr > 0 && (min_st >> log2_wpr) < kMinSteps) log2_wpr--;
-    if (two && log2_wpr == 0) log2_wpr = 1;
-    const int items = items_at(mp, log2_wpr, W);
-    if (items > ncu) return false;
-    for (int j = 0; j < mp.njobs; j++) {
-        TcParams &p = mp.job[j];
-        int sk = 1;
-        const int per_wave = (p.st1 + p.st2 + (1 << log2_wpr) - 1) >> log2_wpr;
-        if (items * 2 <= ncu && log2_wpr == kChainLog2W && out_zeroed[j]) {
-            const int want = ncu / items;
-            while (sk * 2 <= want && per_wave / (sk * 2) >= kMinSteps) sk *= 2;
-        }
-        set_chunks(p, log2_wpr, sk, W);
-    }
-    int total = 0;
-    for (int j = 0; j < kMaxJobs; j++) {
-        if (j < mp.njobs) total += mp.job[j].nitems;
-        mp.item_end[j] = total;
-    }
-    mp.total_items = total;
-    return total <= ncu;
-}
-
-// bytes of LDS beside the codebook image in a chain launch (tc_chain.h: chain_scratch_bytes)
-int chain_scratch(int image_bytes) {
-    const int avail = 160 * 1024 - image_bytes - 1024;
-    return avail > 72 * 1024 ? 72 * 1024 : avail;
-}
-int chain_x_fits(int n, int k, int image_bytes) {
-    return n <= 8 && kChainWaves * 32 * 4 * n + 2 * n * k + 64 <= chain_scratch(image_bytes) && (n * k) % 8 == 0;
-}
 int lut_image_bytes(int bits, int vec) {
     const int idx = vec == 2 ? bits : (bits <= 6 ? 2 * bits : bits);
     const int log2c = (15 - idx) < 5 ? (15 - idx) : 5;
@@ -539,7 +492,7 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
                          : tcq_check(jb.c1, jb.c2, jb.tlut, jb.m, jb.k, S, kv, KV2, split);
         if (rc) return rc;
         if ((!jb.out && !jb.act_out) || (!jb.x && !(jb.x_f32 && jb.x_had))) return QPAL_E_NULL;
-        if (jb.x_f32 && !jb.x_had) return QPAL_E_PARAM;  // fp32 input: rotation staging (or chain launches) only
+        if (jb.x_f32 && !jb.x_had) return QPAL_E_PARAM;  // fp32 input: rotation staging only
         if (jb.act_out && (!jb.x_had || n != 1 || jb.accumulate || (jb.m % 64) || !aligned(jb.act_out, 2))) return QPAL_E_PARAM;
         if ((jb.x && !aligned(jb.x, 8)) || !aligned(jb.out, 4) || (jb.k % 4)) return QPAL_E_ALIGN;
         if (jb.wscale && !aligned(jb.wscale, 2)) return QPAL_E_ALIGN;
@@ -676,7 +629,8 @@ static int lut_args_ok(const void *out, const void *qweight, const void *x, cons
 
 int qpal_lut_tc_gemv(float *out, const void *qweight, const void *x, const void *lut, int m, int n, int k, int bits,
                      int vec, void *stream) {
-    qpal_lut_job job{out, qweight, x, lut, m, k, 0, nullptr, 1.0f, 0, 0, 1.0f, nullptr, nullptr, 1.0f, 0, 0, 0.0f, nullptr, 0};
+    qpal_lut_job job{};
+    job.out = out; job.qweight = qweight; job.x = x; job.lut = lut; job.m = m; job.k = k; job.oscale = 1.0f; job.x_post = 1.0f;
     return qpal_lut_tc_gemv_multi(&job, 1, n, bits, vec, nullptr, 0, stream);
 }
 
@@ -693,7 +647,7 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
         const qpal_lut_job &jb = jobs[j];
         int rc = lut_args_ok(jb.out ? jb.out : jb.act_out, jb.qweight, jb.x ? jb.x : (jb.x_had ? jb.x_f32 : nullptr), jb.lut, jb.m, n, jb.k, bits, vec);
         if (rc) return rc;
-        if (jb.x_f32 && !jb.x_had) return QPAL_E_PARAM;  // fp32 input: rotation staging (or chain launches) only
+        if (jb.x_f32 && !jb.x_had) return QPAL_E_PARAM;  // fp32 input: rotation staging only
         if (jb.act_out && (!jb.x_had || n != 1 || jb.accumulate || (jb.m % 64) || !aligned(jb.act_out, 2))) return QPAL_E_PARAM;
         if (jb.wscale && !aligned(jb.wscale, 2)) return QPAL_E_ALIGN;
         if (jb.ldo != 0 && jb.ldo < jb.m) return QPAL_E_SHAPE;
@@ -747,71 +701,6 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
         if (rc) return rc;
     }
     return launch_lut_tc_gemv(mp, bits, vec, nbg, grid, s);
-}
-
-int qpal_mixed_gemv_multi(const qpal_tcq_job *tcq_jobs, int ntcq, const qpal_lut_job *lut_jobs, int nlut, const int *lut_bits,
-                          const int *lut_vec, int n, int S, void *prezero, long prezero_bytes, void *stream) {
-    if ((ntcq > 0 && !tcq_jobs) || (nlut > 0 && (!lut_jobs || !lut_bits || !lut_vec))) return QPAL_E_NULL;
-    if (ntcq < 0 || nlut < 1 || ntcq + nlut > kMaxJobs) return QPAL_E_SHAPE;
-    if (prezero_bytes < 0 || prezero_bytes % 16 || (prezero_bytes && (!prezero || !aligned(prezero, 16)))) return QPAL_E_ALIGN;
-    if (n < 1 || n > 8) return QPAL_E_SHAPE;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    TcMultiParams mp{};
-    mp.njobs = ntcq + nlut;
-    int zeroed[kMaxJobs] = {0};
-    int ms[kMaxJobs] = {0};
-    const void *x0 = nullptr;
-    int k0 = 0;
-    for (int j = 0; j < ntcq; j++) {
-        const qpal_tcq_job &jb = tcq_jobs[j];
-        if (!jb.kv || jb.x_had || jb.x_f32 || jb.accumulate) return QPAL_E_PARAM;  // per-job KV; no fused rotation here
-        const bool two = jb.kv2 && jb.c2;
-        if (jb.kv2 && !two) return QPAL_E_PARAM;
-        int rc = two ? tcq_check(jb.c1, jb.c2, jb.tlut, jb.m, jb.k, S, jb.kv, jb.kv2, QPAL_SPLIT_COLS)
-                     : tcq_check(jb.c1, nullptr, jb.tlut, jb.m, jb.k, S, jb.kv, 0, QPAL_SPLIT_NONE);
-        if (rc) return rc;
-        for (const int kv : {jb.kv, jb.kv2})
-            if (kv && ((S == 9 && kv > 8) || (S == 10 && kv < 8) || (S == 11 && kv < 9))) return QPAL_E_PARAM;
-        if (!jb.out || !jb.x) return QPAL_E_NULL;
-        if (!aligned(jb.x, 8) || !aligned(jb.out, 4) || (jb.k % 4) || (jb.wscale && !aligned(jb.wscale, 2))) return QPAL_E_ALIGN;
-        if (jb.ldo != 0 && jb.ldo < jb.m) return QPAL_E_SHAPE;
-        const long ldo = jb.ldo ? jb.ldo : jb.m;
-        if (two) tcq_fill(mp.job[j], jb.out, ldo, jb.c1, jb.c2, jb.x, jb.tlut, jb.m, n, jb.k, jb.k / 2, jb.k / 2, jb.wscale, jb.oscale);
-        else tcq_fill(mp.job[j], jb.out, ldo, jb.c1, nullptr, jb.x, jb.tlut, jb.m, n, jb.k, jb.k, 0, jb.wscale, jb.oscale);
-        mp.job[j].kv = jb.kv;
-        mp.job[j].kv2 = two ? jb.kv2 : 0;
-        zeroed[j] = jb.out_zeroed;
-        ms[j] = jb.m;
-        if (!x0) x0 = jb.x, k0 = jb.k;
-        if (jb.x == x0 && jb.k != k0) return QPAL_E_PARAM;
-    }
-    for (int i = 0; i < nlut; i++) {
-        const qpal_lut_job &jb = lut_jobs[i];
-        const int j = ntcq + i, bits = lut_bits[i], vec = lut_vec[i];
-        if (!mix_lut_ok(bits, vec)) return QPAL_E_PARAM;  // codecs whose image fits the TCQ one (tc_kernels.h QPAL_MIX_LUT_CODECS)
-        if (jb.x_had || jb.x_f32 || jb.accumulate) return QPAL_E_PARAM;
-        int rc = lut_args_ok(jb.out, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k, bits, vec);
-        if (rc) return rc;
-        if (jb.wscale && !aligned(jb.wscale, 2)) return QPAL_E_ALIGN;
-        if (jb.ldo != 0 && jb.ldo < jb.m) return QPAL_E_SHAPE;
-        lut_fill(mp.job[j], jb.out, jb.ldo ? jb.ldo : jb.m, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k, jb.wscale, jb.oscale);
-        mp.job[j].kv = vec == 2 ? bits : 2 * bits;  // dwords per lane and supertile (LutCodec::NW)
-        mp.job[j].lut_bits = bits;
-        mp.job[j].lut_vec = vec;
-        zeroed[j] = jb.out_zeroed;
-        ms[j] = jb.m;
-        if (!x0) x0 = jb.x, k0 = jb.k;
-        if (jb.x == x0 && jb.k != k0) return QPAL_E_PARAM;
-    }
-    mp.zero = static_cast<u32x4 *>(prezero);
-    mp.zero_chunks = (int)(prezero_bytes / 16);
-    int grid;
-    plan_launch(mp, zeroed, grid, waves_of(1));
-    for (int j = 0; j < mp.njobs; j++) {
-        int rc = zero_if_split(mp.job[j], ms[j], s, zeroed[j]);
-        if (rc) return rc;
-    }
-    return launch_tcq_gemv_mix(mp, S, grid, s);
 }
 
 int qpal_lut_tc_dequant(void *out_f16, const void *qweight, const void *lut, int m, int k, int bits, int vec,
@@ -869,120 +758,6 @@ int qpal_tc_to_simt(void *dst_simt, const void *src_tc, int m, int k, int bits, 
     hipError_t e = hipMemsetAsync(dst_simt, 0, (size_t)m * k / vec * bits / 8, s);
     if (e != hipSuccess) return (int)e;
     return launch_tc_to_simt(static_cast<uint32_t *>(dst_simt), static_cast<const uint32_t *>(src_tc), m, k, bits, vec, s);
-}
-
-long qpal_chain_blob_bytes(int nphases) {
-    return nphases < 1 ? 0 : (long)sizeof(ChainHeader) + (long)nphases * (long)sizeof(TcMultiParams);
-}
-
-static int chain_build(void *host_blob, long blob_bytes, const qpal_chain_phase *phases, int nphases, int n, int family,
-                       int a, int b, int c, int d, int ncu) {
-    if (!host_blob || !phases) return QPAL_E_NULL;
-    if (nphases < 1 || n < 1 || n > 8 || ncu < 8) return QPAL_E_SHAPE;
-    if (blob_bytes < qpal_chain_blob_bytes(nphases)) return QPAL_E_SHAPE;
-    if (ncu > kNumCU) ncu = kNumCU;
-    ChainHeader h{};
-    h.magic = kChainMagic;
-    h.nphases = nphases;
-    h.grid = ncu;
-    h.family = family;
-    h.a = a; h.b = b; h.c = c; h.d = d;
-    h.n = n;
-    TcMultiParams *out = reinterpret_cast<TcMultiParams *>(static_cast<char *>(host_blob) + sizeof(ChainHeader));
-    const int image = family == 1 ? 64 * 1024 : lut_image_bytes(a, b);
-    for (int ph = 0; ph < nphases; ph++) {
-        const qpal_chain_phase &cp = phases[ph];
-        if (cp.njobs < 1 || cp.njobs > kMaxJobs) return QPAL_E_SHAPE;
-        if (cp.prezero_bytes < 0 || cp.prezero_bytes % 16 || (cp.prezero_bytes && (!cp.prezero || !aligned(cp.prezero, 16))))
-            return QPAL_E_ALIGN;
-        TcMultiParams mp{};
-        mp.njobs = cp.njobs;
-        int zeroed[kMaxJobs] = {0};
-        for (int j = 0; j < cp.njobs; j++) {
-            TcParams &p = mp.job[j];
-            const void *x = nullptr, *x_f32 = nullptr;
-            int x_had = 0, x_fresh = 0, publish = 0, m = 0, k = 0;
-            float x_f32_scale = 1.0f;
-            if (family == 1) {
-                if (!cp.tcq_jobs) return QPAL_E_NULL;
-                const qpal_tcq_job &jb = cp.tcq_jobs[j];
-                if (jb.kv && jb.kv != a) return QPAL_E_PARAM;  // one codec per chain
-                int rc = tcq_check(jb.c1, jb.c2, jb.tlut, jb.m, jb.k, a, b, c, d);
-                if (rc) return rc;
-                if (d == QPAL_SPLIT_ROWS) return QPAL_E_PARAM;
-                if (!jb.out || (!jb.x && !jb.x_f32)) return QPAL_E_NULL;
-                if (jb.ldo != 0 && jb.ldo < jb.m) return QPAL_E_SHAPE;
-                const long ldo = jb.ldo ? jb.ldo : jb.m;
-                if (d == QPAL_SPLIT_NONE)
-                    tcq_fill(p, jb.out, ldo, jb.c1, nullptr, jb.x, jb.tlut, jb.m, n, jb.k, jb.k, 0, jb.wscale, jb.oscale);
-                else
-                    tcq_fill(p, jb.out, ldo, jb.c1, jb.c2, jb.x, jb.tlut, jb.m, n, jb.k, jb.k / 2, jb.k / 2, jb.wscale, jb.oscale);
-                p.kv = b;
-                x = jb.x; x_f32 = jb.x_f32; x_f32_scale = jb.x_f32_scale; x_had = jb.x_had; x_fresh = jb.x_fresh; publish = jb.publish;
-                zeroed[j] = jb.out_zeroed; m = jb.m; k = jb.k;
-            } else {
-                if (!cp.lut_jobs) return QPAL_E_NULL;
-                const qpal_lut_job &jb = cp.lut_jobs[j];
-                int rc = lut_args_ok(jb.out, jb.qweight, jb.x ? jb.x : jb.x_f32, jb.lut, jb.m, n, jb.k, a, b);
-                if (rc) return rc;
-                if (jb.ldo != 0 && jb.ldo < jb.m) return QPAL_E_SHAPE;
-                lut_fill(p, jb.out, jb.ldo ? jb.ldo : jb.m, jb.qweight, jb.x, jb.lut, jb.m, n, jb.k, jb.wscale, jb.oscale);
-                x = jb.x; x_f32 = jb.x_f32; x_f32_scale = jb.x_f32_scale; x_had = jb.x_had; x_fresh = jb.x_fresh; publish = jb.publish;
-                zeroed[j] = jb.out_zeroed; m = jb.m; k = jb.k;
-            }
-            (void)m;
-            if (x_had) return QPAL_E_PARAM;  // rotation: a launch of its own (qpal_hadamard) or the per-launch entry points
-            if (x && !aligned(x, 8)) return QPAL_E_ALIGN;
-            if (x_f32 && !aligned(x_f32, 4)) return QPAL_E_ALIGN;
-            if (p.wscale && !aligned(p.wscale, 2)) return QPAL_E_ALIGN;
-            if (!aligned(p.out, 4) || (k % 4)) return QPAL_E_ALIGN;
-            p.x_lds = chain_x_fits(n, k, image);
-            p.x_f32 = static_cast<const float *>(x_f32);
-            p.x_f32_scale = x_f32_scale == 0.0f ? 1.0f : x_f32_scale;
-            p.x_fresh = x_fresh || x_f32 != nullptr;
-            p.publish = publish;
-            if (!p.x_lds) return QPAL_E_SHAPE;  // the chain kernel stages the activations through LDS only
-        }
-        // all jobs of a phase share one input: one staging per workgroup
-        for (int j = 1; j < cp.njobs; j++) {
-            const TcParams &p0 = mp.job[0], &p = mp.job[j];
-            if (p.x != p0.x || p.x_f32 != p0.x_f32 || p.x_f32_scale != p0.x_f32_scale || p.k != p0.k || p.x_fresh != p0.x_fresh)
-                return QPAL_E_PARAM;
-        }
-        mp.zero = static_cast<u32x4 *>(cp.prezero);
-        mp.zero_chunks = (int)(cp.prezero_bytes / 16);
-        if (!plan_chain_phase(mp, zeroed, ncu)) return QPAL_E_SHAPE;
-        out[ph] = mp;
-    }
-    memcpy(host_blob, &h, sizeof(h));
-    return QPAL_OK;
-}
-
-int qpal_tcq_chain_build(void *host_blob, long blob_bytes, const qpal_chain_phase *phases, int nphases, int n, int S,
-                         int KV1, int KV2, int split, int ncu) {
-    if (split == QPAL_SPLIT_NONE) KV2 = 0;
-    return chain_build(host_blob, blob_bytes, phases, nphases, n, 1, S, KV1, KV2, split, ncu);
-}
-
-int qpal_lut_chain_build(void *host_blob, long blob_bytes, const qpal_chain_phase *phases, int nphases, int n, int bits,
-                         int vec, int ncu) {
-    if (!lut_tc_ok(bits, vec)) return QPAL_E_PARAM;
-    return chain_build(host_blob, blob_bytes, phases, nphases, n, 2, bits, vec, 0, 0, ncu);
-}
-
-int qpal_chain_launch(const void *dev_blob, const void *host_blob, void *dev_ws, void *dbg, void *stream) {
-    if (!dev_blob || !host_blob || !dev_ws) return QPAL_E_NULL;
-    if (!aligned(dev_blob, 16) || !aligned(dev_ws, 128)) return QPAL_E_ALIGN;
-    ChainHeader h;
-    memcpy(&h, host_blob, sizeof(h));
-    if (h.magic != kChainMagic || h.nphases < 1 || h.grid < 8 || h.grid > kNumCU) return QPAL_E_PARAM;
-    const TcMultiParams *phases = reinterpret_cast<const TcMultiParams *>(static_cast<const char *>(dev_blob) + sizeof(ChainHeader));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (h.family == 1) return launch_tcq_chain(phases, h.nphases, static_cast<ChainWs *>(dev_ws), h.a, h.b, h.d == QPAL_SPLIT_NONE ? 0 : h.c,
-                                               h.grid, static_cast<unsigned long long *>(dbg), s);
-    if (h.family == 2) return launch_lut_chain(phases, h.nphases, static_cast<ChainWs *>(dev_ws), h.a, h.b, h.grid,
-                                               static_cast<unsigned long long *>(dbg), s);
-    return QPAL_E_PARAM;
 }
 
 int qpal_can_fuse_rotation(int n, int k) { return n >= 1 && k > 0 && rot_ok(n, k) ? 1 : 0; }

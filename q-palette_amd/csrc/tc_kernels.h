@@ -65,7 +65,6 @@ struct TcParams {
     // 2 nc1 stream-1 chunks of base1 / 2 steps (and base2 / 2 on stream 2).
     int kv;                  // TcqAny kernels only: this job's KV (trellis dwords per lane)
     int kv2;                 // TcqAny kernels only: KV of stream 2 of a column-split (combt) job, 0: single stream
-    int lut_bits, lut_vec;   // TcqMix kernels only: != 0: this job is a VQ/SQ (LutCodec<lut_bits, lut_vec>) layer; kv = its dwords per lane
     const uint16_t *x_su;    // gemv prologue rotation (x_rot != 0): fp16 [k] sign vector or null
     float x_pre, x_post;     //   staged x = fp16( fp16( H_k (x * su) * x_pre ) * x_post ), x_pre = k^-1/2
     int x_rot;               //   0: x is used as given; else k / 1024 (k in {2048, 4096}), or 28: the 14336-wide rotation of rot_k28.h; needs x_lds
@@ -73,11 +72,6 @@ struct TcParams {
     const uint16_t *wscale;  // gemv epilogue: fp16 [m] per-output-row scale or null
     float oscale;            // gemv epilogue: out = acc * wscale[row] * oscale
     unsigned long long *dbg;  // QPAL_STAMPS diagnostic builds only: per-wave s_memtime stamps
-    // chain launches only (tc_chain.h): data handed from phase to phase inside one launch
-    const float *x_f32;      // staged x = fp16(x_f32[i] * x_f32_scale): the fp32 output of an earlier phase (agent-scope loads)
-    float x_f32_scale;
-    int x_fresh;             // x (fp16) was written by an earlier phase of this launch: agent-scope loads
-    int publish;             // out is read by a later phase of this launch: agent-scope (write-through) stores
     // decoder-block fusion (x_rot jobs of the per-launch kernels): the rotation's input may be the fp32 residual stream
     // with RMSNorm applied on the way in, and the projection may accumulate into its output (the residual add)
     int x_src_f32;           // x points at fp32 [k] (not fp16)
@@ -624,33 +618,6 @@ __device__ __forceinline__ void dispatch_kv(int kv, F &&f) {
     });
 }
 
-// Mixed-FAMILY launches: a mixed-scheme model's q | k | v are often TCQ and VQ/SQ layers side by side.  TcqMix<S> = TcqAny<S>
-// whose job table may also hold VQ/SQ (tensor-core packing) jobs of the codecs below — those whose image is no larger than
-// the TCQ one, so the LDS allocation is unchanged; a workgroup builds the image of the job it works on and switches to that
-// family's decode loop (workgroup-uniform; the instruction cache of a CU only ever sees the loops of the jobs it runs).
-template <int S>
-struct TcqMix : TcqAny<S> {
-    static constexpr bool kMix = true;
-    static constexpr int NW = 16;  // registers for the widest member: LutCodec<8, 1>
-};
-template <class C>
-constexpr bool is_mix_v = requires { C::kMix; };
-
-#define QPAL_MIX_LUT_CODECS(X) X(2, 2) X(3, 2) X(4, 2) X(5, 2) X(6, 2) X(7, 2) X(8, 2) X(2, 1) X(3, 1) X(4, 1) X(7, 1) X(8, 1)
-inline bool mix_lut_ok(int bits, int vec) {
-#define QPAL_X(B_, V_) if (bits == B_ && vec == V_) return true;
-    QPAL_MIX_LUT_CODECS(QPAL_X)
-#undef QPAL_X
-    return false;
-}
-// f(LutCodec<bits, vec>{}) for the runtime (bits, vec) of a job (uniform across the workgroup)
-template <class F>
-__device__ __forceinline__ void dispatch_lut(int bits, int vec, F &&f) {
-#define QPAL_X(B_, V_) if (bits == B_ && vec == V_) f(LutCodec<B_, V_>{});
-    QPAL_MIX_LUT_CODECS(QPAL_X)
-#undef QPAL_X
-}
-
 // ------------------------------------------------------------------------------------------------
 // Fused decode + GEMV / skinny GEMM, 1 <= n <= 8*NBG.  1024 threads (16 waves, 4 per SIMD), one workgroup per
 // CU (LDS-bound).  C2 == void: single stream.  Otherwise combt (columns [0,col2) from c1 via C1, the rest from
@@ -785,7 +752,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     // the first weight loads have been issued)
     constexpr int NV = (C1::CHUNKS + NT - 1) / NT;
     // (the 128 KiB images of the wide VQ/SQ codebooks would hold 8 entries per thread: spills, measured 20-30 % slower)
-    // <= 4 entries per thread of a 16-wave workgroup.  NOT in the any-KV / mixed-family kernels (round 3): holding the early values
+    // <= 4 entries per thread of a 16-wave workgroup.  NOT in the any-KV kernels in round 3: holding the early values
     // across their seven decode loops' set-up spilled 16-28 VGPRs, and a kernel that touches scratch at all pays ~1 us per
     // launch — without early staging they have no spills and the q | k | v launch of a mixed-scheme model takes 7.1 instead of
     // 8.3 us (llama3.1-8b_figure1c 651 -> 707 tok/s, mem3p25 678 -> 722, one box: profiles/r03_ab_any_spills.txt).
@@ -795,7 +762,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
 #ifndef QPAL_ANY_EARLY
 #define QPAL_ANY_EARLY 1  // round 4: with the early loads outside the compiler's bookkeeping (inline asm) and the first item as its own
 #endif                    // body, the any-KV kernels hold them without spilling (round 3: 16-28 spilled VGPRs, early staging off)
-    constexpr bool kEarly = NBG == 1 && (ROT == 0 || ROT == 3) && NV * NT <= 4096 && (QPAL_ANY_EARLY || !is_any_v<C1>) && !is_mix_v<C1>;
+    constexpr bool kEarly = NBG == 1 && (ROT == 0 || ROT == 3) && NV * NT <= 4096 && (QPAL_ANY_EARLY || !is_any_v<C1>);
     constexpr int EV = NV < 4 ? NV : 4;  // image entries a thread holds across the argument fetch; the rest are built after it
     constexpr int XR = kEarlyXChunks;    // 16-byte chunks of x a thread holds likewise
     [[maybe_unused]] u32x4 exr[XR];
@@ -1084,21 +1051,11 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
             }
         }
         // first step's weights are in flight while x and the codebook image are (re)staged
-        bool lut_job = false;  // workgroup-uniform
-        if constexpr (is_mix_v<C1>) lut_job = p.lut_bits != 0;
         if constexpr (ANY) {
-            if constexpr (is_mix_v<C1>) {
-                if (lut_job)
-                    dispatch_lut(p.lut_bits, p.lut_vec, [&](auto cc) {
-                        using CL = decltype(cc);
-                        load_step_w<CL::NW>(sv1, s0, lane, reinterpret_cast<uint32_t(&)[CL::NW]>(w.a));
-                    });
-            }
-            if (!lut_job)
-                dispatch_kv<C1::S_>(on2 ? p.kv2 : p.kv, [&](auto kc) {
-                    constexpr int KVr = decltype(kc)::value;
-                    load_step_w<KVr>(on2 ? sv2 : sv1, s0, lane, reinterpret_cast<uint32_t(&)[KVr]>(w.a));
-                });
+            dispatch_kv<C1::S_>(on2 ? p.kv2 : p.kv, [&](auto kc) {
+                constexpr int KVr = decltype(kc)::value;
+                load_step_w<KVr>(on2 ? sv2 : sv1, s0, lane, reinterpret_cast<uint32_t(&)[KVr]>(w.a));
+            });
         } else {
             if constexpr (TWO) {
                 if (on2) load_step_w<CB::NW>(sv2, s0, lane, w.b);
@@ -1271,18 +1228,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                 cur_x = p.x;
             }
             if (p.tab != cur_tab) {
-                bool built = false;
-                if constexpr (is_mix_v<C1>) {
-                    if (p.lut_bits) {
-                        dispatch_lut(p.lut_bits, p.lut_vec, [&](auto cc) {
-                            using CL = decltype(cc);
-                            static_assert(CL::LDS_DWORDS <= C1::LDS_DWORDS, "a mixed launch keeps the TCQ image's LDS allocation");
-                            CL::build(lut, p.tab, tid, NT);
-                        });
-                        built = true;
-                    }
-                }
-                if (!built) C1::build(lut, p.tab, tid, NT);
+                C1::build(lut, p.tab, tid, NT);
                 cur_tab = p.tab;
             }
             QPAL_STAMP(2);
@@ -1305,17 +1251,6 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         if (p.wscale && tid < (32 << log2_rpw) && row_of(tid >> 5) < p.nrows)
             wraw = p.wscale[row_of(tid >> 5) * 32 + (tid & 31)];
         if constexpr (ANY) {
-            if constexpr (is_mix_v<C1>) {
-                if (lut_job)
-                    dispatch_lut(p.lut_bits, p.lut_vec, [&](auto cc) {
-                        using CL = decltype(cc);
-                        auto &wk = reinterpret_cast<uint32_t(&)[CL::NW]>(w.a);
-                        const uint32_t lo = (uint32_t)(lane & (CL::C - 1)) << 2;
-                        if (NBG == 1 && x_lds) gemv_run<CL, kXL, NBG>(wk, lut, lo, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-                        else gemv_run<CL, 0, NBG>(wk, lut, lo, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-                    });
-            }
-            if (!lut_job)
             dispatch_kv<C1::S_>(on2 ? p.kv2 : p.kv, [&](auto kc) {
                 constexpr int KVr = decltype(kc)::value;
                 using CK = TcqCodec<C1::S_, KVr>;

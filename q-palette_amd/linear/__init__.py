@@ -77,44 +77,12 @@ def _launch_key(layer, mixed_kv):
     return key
 
 
-def _mix_lut_ok(layer):
-    from .. import ops
-    return isinstance(layer, VQLinearPackTensorCore) and (layer.lut_bits, layer.vec_sz) in ops.MIX_LUT_CODECS
-
-
-def launch_groups(layers, mixed_kv=False, mixed_family=None):
+def launch_groups(layers, mixed_kv=False):
     """Partition `layers` (projections of one input) into multi-job launches: lists of indices, at most 8 each.
-    mixed_kv: TCQ layers of one codebook size share a launch whatever their KV (any-KV kernel).  mixed_family (default: the
-    environment's QPAL_MIXED_FAMILY=1): VQ/SQ layers with small codebook images also join them, or each other, through the
-    mixed-family kernel — OFF by default: on the published mixed-scheme models it saves 4-6 launches per token and loses more
-    than that in the launches it takes over (no preloaded-argument prologue, 252 bytes of spills: 650 vs 691 tokens/s)."""
-    if mixed_family is None:
-        mixed_family = os.environ.get("QPAL_MIXED_FAMILY") == "1"
+    mixed_kv: TCQ layers of one codebook size share a launch whatever their KV (any-KV kernel)."""
     groups = {}
     for i, layer in enumerate(layers):
         groups.setdefault(_launch_key(layer, mixed_kv), []).append(i)
-    if mixed_kv and mixed_family:
-        # VQ/SQ layers the mixed-family kernel can hold join the (first) any-KV TCQ group of their input width; without one,
-        # VQ/SQ layers of different codecs join each other
-        hosts = {}
-        for key in groups:
-            if key[0] == "tcq" and key[-1] == "any":
-                hosts.setdefault(key[1], key)
-        pooled = {}
-        for key in [k for k in groups if k[0] == "lut_tc"]:
-            if not all(_mix_lut_ok(layers[i]) for i in groups[key]):
-                continue
-            host = hosts.get(key[1])
-            if host is not None:
-                groups[host] += groups.pop(key)
-            else:
-                pooled.setdefault(key[1], []).append(key)
-        for k_in, keys in pooled.items():
-            if len(keys) > 1:
-                merged = sorted(i for key in keys for i in groups.pop(key))
-                groups[("lut_mix", k_in)] = merged
-        for key in groups:
-            groups[key].sort()
     out = []
     for key, idxs in groups.items():
         if key[0] == "single":
@@ -225,7 +193,7 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
             return full
         return [l(x2) for l in layers]  # decode-to-fp16 + GEMM path of the modules
     results = [None] * len(layers)
-    mixed_kv = x_rot is None and n <= 8 and not accumulate  # the any-KV / mixed-family kernels: no rotation, batch <= 8
+    mixed_kv = x_rot is None and n <= 8 and not accumulate  # the any-KV kernels: no rotation, batch <= 8
     for idxs in launch_groups(layers, mixed_kv):
         first = layers[idxs[0]]
         kind = _codec_key(first)[0]
@@ -234,24 +202,7 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
         ws = [wscales[i] for i in idxs] if wscales is not None else None
         extra = dict(outs=o, outs_zeroed=outs_zeroed, prezero=prezero, wscales=ws, oscale=oscale, x_rot=x_rot, x_rms=x_rms,
                      accumulate=accumulate)
-        if any(isinstance(l, VQLinearPackTensorCore) for l in grp) and len({_codec_key(l) for l in grp}) > 1:
-            # TCQ and VQ/SQ layers (or VQ/SQ layers of different codecs) in one launch: the mixed-family kernel
-            tq = [i for i, l in enumerate(grp) if not isinstance(l, VQLinearPackTensorCore)]
-            lq = [i for i, l in enumerate(grp) if isinstance(l, VQLinearPackTensorCore)]
-            order = tq + lq
-            tjobs = [(grp[i].trellis, None, grp[i].tlut, grp[i].out_features, grp[i].KV) if isinstance(grp[i], QTIPLinearTCQ)
-                     else (grp[i].trellis1, grp[i].trellis2, grp[i].tlut, grp[i].out_features, grp[i].KV[0], grp[i].KV[1]) for i in tq]
-            ljobs = [(grp[i].qweight, grp[i].lut, grp[i].out_features, grp[i].lut_bits, grp[i].vec_sz) for i in lq]
-            S = grp[tq[0]].tlut_bits if tq else 9
-            mo = [o[i] for i in order] if o is not None else None
-            mw = [ws[i] for i in order] if ws is not None else None
-            got = ops.mixed_gemv_multi(tjobs, ljobs, x2, S, outs=mo, outs_zeroed=outs_zeroed, prezero=prezero, wscales=mw,
-                                       oscale=oscale)
-            ys = [None] * len(grp)
-            for pos_, i in enumerate(order):
-                ys[i] = got[pos_]
-            prezero = None
-        elif kind == "tcq" or (kind == "tcombt" and any(_codec_key(l) != _codec_key(first) for l in grp)):
+        if kind == "tcq" or (kind == "tcombt" and any(_codec_key(l) != _codec_key(first) for l in grp)):
             # one codec: its own kernel; different KV / single- and two-stream layers mixed: the any-KV kernel (per-job KV)
             jobs = [(l.trellis, None, l.tlut, l.out_features, l.KV) if isinstance(l, QTIPLinearTCQ)
                     else (l.trellis1, l.trellis2, l.tlut, l.out_features, l.KV[0], l.KV[1]) for l in grp]

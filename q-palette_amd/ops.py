@@ -378,7 +378,7 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
                              xh.data_ptr() if xh is not None else None, tl.data_ptr(), m, k,
                              1 if (outs is not None and outs_zeroed) else 0,
                              _wscale_arg(wscales, j, m), float(oscale), _ldo(out, n, m) if out is not None else 0, had, xpost, xsu, kv,
-                             x32.data_ptr() if x32 is not None else None, 1.0, 0, 0, rms_eps, rms_w, 1 if accumulate else 0, kv2,
+                             x32.data_ptr() if x32 is not None else None, rms_eps, rms_w, 1 if accumulate else 0, kv2,
                              act.data_ptr() if act is not None else None, xhadk, xK, _act_su_arg(act_su, act, m))
         results.append(out)
         keep += [c1, c2, tl]
@@ -411,7 +411,7 @@ def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezer
         jobs[j] = nat.LutJob(out.data_ptr() if out is not None else None, q.data_ptr(), xh.data_ptr() if xh is not None else None,
                              cb.data_ptr(), m, k, 1 if (outs is not None and outs_zeroed) else 0, _wscale_arg(wscales, j, m),
                              float(oscale), _ldo(out, n, m) if out is not None else 0, had, xpost, xsu,
-                             x32.data_ptr() if x32 is not None else None, 1.0, 0, 0, rms_eps, rms_w, 1 if accumulate else 0,
+                             x32.data_ptr() if x32 is not None else None, rms_eps, rms_w, 1 if accumulate else 0,
                              act.data_ptr() if act is not None else None, xhadk, xK, _act_su_arg(act_su, act, m))
         results.append(out)
         keep += [q, cb]
@@ -419,58 +419,6 @@ def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezer
     with torch.cuda.device_of(x):
         rc = nat.lib().qpal_lut_tc_gemv_multi(jobs, len(layers), n, bits, vec, zp, zb, _stream(x))
     nat.check(rc, "qpal_lut_tc_gemv_multi")
-    return results
-
-
-MIX_LUT_CODECS = {(b, 2) for b in range(2, 9)} | {(2, 1), (3, 1), (4, 1), (7, 1), (8, 1)}  # csrc/tc_kernels.h QPAL_MIX_LUT_CODECS
-
-
-def mixed_gemv_multi(tcq_streams, lut_layers, x, S, outs=None, outs_zeroed=False, prezero=None, wscales=None, oscale=1.0):
-    """TCQ layers of codebook size S (streams as in tcq_gemv_multi, every one with its KV: (c1, None, tlut, m, KV) or
-    (c1, c2, tlut, m, KV, KV2)) and VQ/SQ tensor-core-packing layers ((qweight, lut, m, bits, vec), codecs of MIX_LUT_CODECS) of
-    one input in ONE launch (C-ABI qpal_mixed_gemv_multi).  outs / wscales are indexed TCQ layers first, then VQ/SQ layers;
-    returns the outputs in that order."""
-    n, k = x.shape
-    _chk(1 <= n <= 8, "mixed-family launches: batch 1..8")
-    _chk(len(lut_layers) >= 1 and len(tcq_streams) + len(lut_layers) <= 8, "1..8 jobs, at least one VQ/SQ layer")
-    xh, _ = _x_arg(x, None)
-    nt = len(tcq_streams)
-    tj = (nat.TcqJob * max(nt, 1))()
-    lj = (nat.LutJob * len(lut_layers))()
-    results, keep = [], [xh]
-    zeroed = 1 if (outs is not None and outs_zeroed) else 0
-    for j, stream in enumerate(tcq_streams):
-        c1, c2, tlut, m, kv = stream[:5]
-        kv2 = stream[5] if len(stream) > 5 else 0
-        c1, tl = _dev(c1, "compressed1"), _dev(tlut, "codebook")
-        _chk(tl.dtype == torch.float16 and tl.numel() == 2 << S, f"codebook must be fp16 with {2 << S} elements")
-        if kv2:
-            c2 = _dev(c2, "compressed2")
-            _tcq_stream_ok(c1, m, k // 2, kv, "compressed1")
-            _tcq_stream_ok(c2, m, k // 2, kv2, "compressed2")
-        else:
-            c2 = None
-            _tcq_stream_ok(c1, m, k, kv, "compressed")
-        out = _out_arg(outs, j, n, m, x.device)
-        tj[j] = nat.TcqJob(out.data_ptr(), c1.data_ptr(), c2.data_ptr() if c2 is not None else None, xh.data_ptr(), tl.data_ptr(), m, k,
-                           zeroed, _wscale_arg(wscales, j, m), float(oscale), _ldo(out, n, m), 0, 0.0, None, kv, None, 1.0, 0, 0,
-                           0.0, None, 0, kv2, None)
-        results.append(out)
-        keep += [c1, c2, tl]
-    bits_a, vec_a = (ctypes.c_int * len(lut_layers))(), (ctypes.c_int * len(lut_layers))()
-    for i, (q, lut, m, bits, vec) in enumerate(lut_layers):
-        _chk((bits, vec) in MIX_LUT_CODECS, f"VQ/SQ codec ({bits} bits, vec {vec}) cannot join a mixed-family launch")
-        q, cb = _lut_args(q, lut, m, k, bits, vec)
-        out = _out_arg(outs, nt + i, n, m, x.device)
-        lj[i] = nat.LutJob(out.data_ptr(), q.data_ptr(), xh.data_ptr(), cb.data_ptr(), m, k, zeroed, _wscale_arg(wscales, nt + i, m),
-                           float(oscale), _ldo(out, n, m), 0, 0.0, None, None, 1.0, 0, 0, 0.0, None, 0, None)
-        bits_a[i], vec_a[i] = bits, vec
-        results.append(out)
-        keep += [q, cb]
-    zp, zb = _prezero_args(prezero)
-    with torch.cuda.device_of(x):
-        rc = nat.lib().qpal_mixed_gemv_multi(tj, nt, lj, len(lut_layers), bits_a, vec_a, n, S, zp, zb, _stream(x))
-    nat.check(rc, "qpal_mixed_gemv_multi")
     return results
 
 

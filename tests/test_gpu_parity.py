@@ -515,19 +515,16 @@ def test_tcomb_and_tcq_projections_share_one_launch(qp, oracle):
     assert sorted(len(g) for g in qp.linear.launch_groups([mods[0], far], mixed_kv=True)) == [1, 1]
 
 
-def test_tcq_and_vq_sq_projections_share_one_launch(qp, oracle, monkeypatch):
-    """Mixed-FAMILY q | k | v (the reference's MSQ results give every projection its own quantizer): TCQ layers of any KV,
-    column-split tcomb layers and VQ/SQ tensor-core-packing layers with small codebook images go out as ONE launch
-    (qpal_mixed_gemv_multi: the workgroup builds the image of the job it works on and runs that family's decode loop); VQ/SQ
-    layers of different codecs without a TCQ neighbour share a launch too; wide codebooks stay on their own.  (Opt-in:
-    QPAL_MIXED_FAMILY=1 — measured slower than separate launches on the published models)"""
-    monkeypatch.setenv("QPAL_MIXED_FAMILY", "1")
+def test_mixed_family_projections_one_launch_per_family(qp, oracle):
+    """Mixed-FAMILY q | k | v (the reference's MSQ results give every projection its own quantizer): TCQ layers of one codebook
+    size (any KV, column-split tcomb layers too) share ONE any-KV launch; every VQ/SQ codec is a launch of its own (a kernel that
+    switched families per job measured slower than separate launches and was removed in round 5)."""
     k = 4096
-    cases = ((("tcq_3_none_0.9", "ldlq_2_6_none_1.0", "tcomb_4_5_0.5_none_0.9"), (4096, 1024, 1024), [3]),
+    cases = ((("tcq_3_none_0.9", "ldlq_2_6_none_1.0", "tcomb_4_5_0.5_none_0.9"), (4096, 1024, 1024), [1, 2]),
              (("ldlq_2_8_none_1.0", "tcq_7_none_0.9", "ldlq_1_4_none_1.0", "ldlq_1_8_none_1.0", "tcomb_6_7_0.5_none_0.9"),
-              (14336, 512, 4096, 96, 2048), [5]),
-             (("ldlq_2_3_none_1.0", "ldlq_1_7_none_1.0", "ldlq_2_5_none_1.0"), (1024, 1024, 4096), [3]),
-             (("tcq_4_none_0.9", "ldlq_2_10_none_1.0", "ldlq_1_6_none_1.0", "ldlq_2_4_none_1.0"), (1024, 512, 512, 256), [1, 1, 2]))
+              (14336, 512, 4096, 96, 2048), [1, 1, 1, 2]),
+             (("ldlq_2_3_none_1.0", "ldlq_1_7_none_1.0", "ldlq_2_5_none_1.0"), (1024, 1024, 4096), [1, 1, 1]),
+             (("tcq_4_none_0.9", "ldlq_2_10_none_1.0", "ldlq_1_6_none_1.0", "ldlq_2_4_none_1.0"), (1024, 512, 512, 256), [1, 1, 1, 1]))
     for qstrs, ms, want_sizes in cases:
         layers = []
         for i, (qstr, m) in enumerate(zip(qstrs, ms)):
