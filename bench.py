@@ -240,6 +240,11 @@ def build_model(qp, torch, model_key, qstr, nlayers, device, shard=None, distinc
 KINDS = ["q|k|v", "o", "gate|up", "down"]  # the four dependent multi-job launches of a decoder block
 
 
+def _kind_on(only_kind, gi):
+    """only_kind: None (every launch kind), one kind index, or a collection of them"""
+    return only_kind is None or (gi in only_kind if hasattr(only_kind, "__contains__") else only_kind == gi)
+
+
 def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=False, gather=None, side=(), main_stream=None,
                only_kind=None):
     """-> (token, None): token() runs every quantized linear of `layers` once (one decoded token at batch n, plain inputs
@@ -331,11 +336,11 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
                     # this group's block was zeroed by the launch before it iff that launch was a multi-job launch of packed layers
                     prev_zeroed = pli >= 0 and owned[pli][pgi] is not None
                     if owned[li][gi] is None:  # a SIMT-packed layer in the group: plain launches (nothing zeroes the next block)
-                        if only_kind is None or only_kind == gi:
+                        if _kind_on(only_kind, gi):
                             outs += qp.multi_gemv([m for m, _, _ in grp], xs[grp[0][1]])
                         continue
                     flat, views = owned[li][gi]
-                    if only_kind is None or only_kind == gi:
+                    if _kind_on(only_kind, gi):
                         ys = qp.multi_gemv([m for m, _, _ in grp], xs[grp[0][1]], outs=views, outs_zeroed=prev_zeroed, prezero=nxt)
                         # row-sharded model (--parallel tp, tp_70b): the outputs of o_proj / down_proj feed full-width consumers
                         # (the next block's rotation): all-gather them.  q|k|v stay head-sharded through attention, gate|up
@@ -356,7 +361,7 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
                 if n > min(m.max_fused_batch for m in mods) and gather is None:
                     # beyond the fused batch: decode to fp16 W (staged 16-byte stores) + fp16 GEMM, as the reference does for
                     # bs > 8 (lib/linear/tcq_linear.py:75-84); the MFMA roofline of this path is reported by --batch
-                    if only_kind is None or only_kind == gi:
+                    if _kind_on(only_kind, gi):
                         outs += qp.multi_gemv(mods, x)   # passes of the fused launches up to max_chunked_batch, decode + GEMM above
                     continue
                 if launch == "multi" and gather is None:
@@ -366,9 +371,9 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
                     nxt = gi + 1
                     if gi in (0, 2) and not no_prezero and len(groups[nxt]) == 1:
                         pre[nxt] = torch.empty((n, groups[nxt][0][0].out_features), dtype=torch.float32, device=device)
-                        if only_kind is None or only_kind == gi:
+                        if _kind_on(only_kind, gi):
                             outs += qp.multi_gemv(mods, x, prezero=pre[nxt])
-                    elif only_kind is not None and only_kind != gi:
+                    elif not _kind_on(only_kind, gi):
                         pass
                     elif gi in pre:
                         outs += qp.multi_gemv(mods, x, outs=[pre[gi]], outs_zeroed=True)
@@ -826,7 +831,8 @@ def main():
         try:
             by_kind = {}
             with torch.cuda.stream(main_stream):
-                for gi, kname in enumerate(KINDS):
+                kinds = list(enumerate(KINDS)) + ([((0, 1), "q|k|v+o"), ((2, 3), "gate|up+down")] if os.environ.get("QPAL_KIND_PAIRS") else [])
+                for gi, kname in kinds:
                     ktoken, _ = make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=args.no_prezero,
                                            only_kind=gi)
                     ktoken()
@@ -844,8 +850,9 @@ def main():
                         kg.replay()
                     k1.record(main_stream)
                     torch.cuda.synchronize()
-                    kbytes = algorithmic_bytes(qp, [[groups[gi]] for groups in layers], n)
-                    nk = sum(len(qp.linear.launch_groups([m for m, _, _ in groups[gi]], mixed_kv=n <= 8)) for groups in layers)
+                    gis = gi if isinstance(gi, tuple) else (gi,)
+                    kbytes = algorithmic_bytes(qp, [[groups[g_] for g_ in gis] for groups in layers], n)
+                    nk = sum(len(qp.linear.launch_groups([m for m, _, _ in groups[g_]], mixed_kv=n <= 8)) for groups in layers for g_ in gis)
                     t_k = k0.elapsed_time(k1) / 1e3 / reps
                     by_kind[kname] = {"launches": nk, "bytes_per_launch": kbytes / nk, "us_per_launch": t_k / nk * 1e6,
                                       "achieved_GBps": kbytes / t_k / 1e9, "frac": kbytes / t_k / 1e9 / HBM_PEAK_GBS}
