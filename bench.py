@@ -28,7 +28,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TP_ABANDONED_RC = 75  # (EX_TEMPFAIL) --strict-exit: the multi-GPU leg was abandoned; the headline line was still printed
+TP_ABANDONED_RC = 75  # (EX_TEMPFAIL) the multi-GPU leg was abandoned / raised / lost a rank; the headline line was still printed
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
 WORKLOADS = {
@@ -89,13 +89,18 @@ def parse_args():
     ap.add_argument("--no-fuse-rotation", action="store_true",
                     help="--incoherent: always rotate in a launch of its own (default: inside the GEMV where k allows)")
     ap.add_argument("--layers", type=int, default=0, help="override the number of layers (0 = model's)")
-    ap.add_argument("--strict-exit", action="store_true",
-                    help=f"exit with code {TP_ABANDONED_RC} (instead of 0) when the tp_70b leg of an N > 1 run was abandoned or a rank died in "
-                         "it; the headline line is printed either way and carries \"tp_70b_abandoned\": true")
+    ap.add_argument("--strict-exit", action="store_true", help="(the default since round 5; accepted for older command lines)")
+    ap.add_argument("--lenient-exit", action="store_true",
+                    help=f"exit with code 0 instead of {TP_ABANDONED_RC} when the tp_70b leg of an N > 1 run was abandoned, raised, or a rank "
+                         "died in it (default: a multi-GPU leg that did not complete FAILS the run — the headline line, measured before "
+                         "the leg, is printed either way and carries \"tp_70b_abandoned\": true)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo to rehearse ranks on one GPU")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: put every rank on this GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `other_configs` key of the default N = 1 run (BASELINE configs[2..4]: mem3p25, figure1d, figure1c, the 70B "
+                         "shapes at batch 1 and 16 — <= 10 steps each, after the headline's timed region)")
     ap.add_argument("--no-whole-model", action="store_true",
                     help="skip the `whole_model_decode` figure of the default N = 1 run (the fused decode step of perf/decode_llama.py)")
     ap.add_argument("--no-tp-leg", action="store_true",
@@ -151,8 +156,8 @@ def spawn_ranks(n):
             print(json.dumps(out), flush=True)
             print(f"[bench] a rank died inside the tp_70b leg (exit code {rc}); the headline line above was measured before it",
                   file=sys.stderr, flush=True)
-            # the measured headline is reported with exit code 0 unless the caller asked for a failing code (--strict-exit)
-            rc = TP_ABANDONED_RC if "--strict-exit" in sys.argv else 0
+            # the measured headline is out; the run still FAILS (a multi-GPU leg that lost a rank must be visible in the exit code)
+            rc = 0 if "--lenient-exit" in sys.argv else TP_ABANDONED_RC
         finally:
             os.remove(park)
     return rc
@@ -247,7 +252,7 @@ def _kind_on(only_kind, gi):
 
 def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=False, gather=None, side=(), main_stream=None,
                only_kind=None):
-    """-> (token, None): token() runs every quantized linear of `layers` once (one decoded token at batch n, plain inputs
+    """-> (token, owned): token() runs every quantized linear of `layers` once (one decoded token at batch n, plain inputs
     xs[in_features]) and returns the outputs in model order.  Also what tests/test_bench_workloads.py drives for the published
     mixed-scheme workloads.
     only_kind (multi-job launches only): run just launch kind 0..3 of every block, with exactly the arguments it has inside
@@ -405,7 +410,8 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
                     outs.append(y)
         return outs
 
-    return token, None
+    # (second value: the harness-owned output blocks [block][launch kind] -> flat fp32 tensor or None; None when the library owns them)
+    return token, ([[g[0] if g is not None else None for g in per] for per in owned] if owned is not None else None)
 
 
 def algorithmic_bytes(qp, layers, batch):
@@ -659,6 +665,18 @@ def main():
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    # Who is in this run: backend, world size and every rank's device as the RANK sees it (index, PCI address, name) — so that a
+    # multi-GPU record shows N ranks on N distinct devices (and a rehearsal with every rank on one card shows that too).
+    prop = torch.cuda.get_device_properties(device)
+    me = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": torch.cuda.current_device(),
+          "pci_bus_id": "%04x:%02x:%02x.0" % (getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", 0), getattr(prop, "pci_device_id", 0)),
+          "uuid": str(getattr(prop, "uuid", "")), "name": prop.name, "pid": os.getpid()}
+    seen = [me]
+    if world > 1:
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+    ranks_seen = {"backend": (dist.get_backend() if world > 1 else None), "world_size": world, "ranks": seen,
+                  "distinct_devices": len({(r_["pci_bus_id"], r_["uuid"]) for r_ in seen})}
 
     import qpalette_amd as qp
     qp._native.lib()
@@ -833,8 +851,8 @@ def main():
             with torch.cuda.stream(main_stream):
                 kinds = list(enumerate(KINDS)) + ([((0, 1), "q|k|v+o"), ((2, 3), "gate|up+down")] if os.environ.get("QPAL_KIND_PAIRS") else [])
                 for gi, kname in kinds:
-                    ktoken, _ = make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=args.no_prezero,
-                                           only_kind=gi)
+                    ktoken, kowned = make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=args.no_prezero,
+                                                only_kind=gi)
                     ktoken()
                     torch.cuda.synchronize()
                     kg = torch.cuda.CUDAGraph()
@@ -843,17 +861,24 @@ def main():
                     for _ in range(3):
                         kg.replay()
                     torch.cuda.synchronize()
-                    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    reps = max(5, min(args.steps, 50))
-                    k0.record(main_stream)
-                    for _ in range(reps):
-                        kg.replay()
-                    k1.record(main_stream)
-                    torch.cuda.synchronize()
+                    # Inside the token every output block is zeroed by the launch BEFORE it; a graph of one kind alone has no such
+                    # launch, and the pair-mode / split-K atomics of o / down / gate|up would pile replay upon replay onto stale sums.
+                    # The harness zeroes the kind's blocks between the replays, OUTSIDE the timed spans (one event pair per replay),
+                    # so the launches timed here run on exactly the inputs they have inside the token.
                     gis = gi if isinstance(gi, tuple) else (gi,)
+                    kblocks = [per[g_] for per in (kowned or []) for g_ in gis if per[g_] is not None]
+                    reps = max(5, min(args.steps, 50))
+                    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+                    for k0, k1 in evs:
+                        for blk in kblocks:
+                            blk.zero_()
+                        k0.record(main_stream)
+                        kg.replay()
+                        k1.record(main_stream)
+                    torch.cuda.synchronize()
                     kbytes = algorithmic_bytes(qp, [[groups[g_] for g_ in gis] for groups in layers], n)
                     nk = sum(len(qp.linear.launch_groups([m for m, _, _ in groups[g_]], mixed_kv=n <= 8)) for groups in layers for g_ in gis)
-                    t_k = k0.elapsed_time(k1) / 1e3 / reps
+                    t_k = sum(k0.elapsed_time(k1) for k0, k1 in evs) / 1e3 / reps
                     by_kind[kname] = {"launches": nk, "bytes_per_launch": kbytes / nk, "us_per_launch": t_k / nk * 1e6,
                                       "achieved_GBps": kbytes / t_k / 1e9, "frac": kbytes / t_k / 1e9 / HBM_PEAK_GBS}
         except Exception as exc:  # the headline line must not depend on this leg
@@ -928,7 +953,8 @@ def main():
                                "owned by the harness, every launch zeroes the next launch's block (the library may split K / pair "
                                "workgroups without memset nodes; QPAL_PAIR=" + os.environ.get("QPAL_PAIR", "1") + ")"),
                    "incoherent": bool(args.incoherent),
-                   "rotation_launches_per_token": nrot[0] if args.incoherent else 0},
+                   "rotation_launches_per_token": nrot[0] if args.incoherent else 0,
+                   "ranks_seen": ranks_seen},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
                      "traffic_source": traffic_source(),
@@ -955,12 +981,13 @@ def main():
         out["with_incoherence_wrapper"] = extra
     if isinstance(gather, qp.shard.PeerGatherer):
         assert gather.error() == 0, "a peer gather gave up waiting for a flag: the figures above are invalid"
-        out["config"]["peer_gather"] = {"flag_memory": gather.flag_memory, "world": world}
+        out["config"]["peer_gather"] = {"flag_memory": gather.flag_memory, "buffer_memory": gather.buffer_memory, "world": world}
     if os.environ.get("QPAL_BENCH_SHARED_WEIGHTS"):
         # experiment knob (cache-resident weights): NOT the benchmark — say so where the number is read
         out["config"]["INVALID_experiment_knob"] = "QPAL_BENCH_SHARED_WEIGHTS: every layer aliases layer 0's buffers"
         out["metric"] = "EXPERIMENT (shared weights), not the headline metric"
     printed = [False]
+    tp_failed = [False]
     watchdog = None
     if world > 1 and not args.no_tp_leg and not tp:
         # BASELINE configs[4]: Llama-3.1-70B shapes @3.0 b row-sharded over the N GPUs, batch 1 and batch 16 (strong scaling),
@@ -970,18 +997,28 @@ def main():
         # and everything after it: on expiry rank 0 prints the line with the leg marked abandoned, and every rank leaves.
         import threading
 
+        fail_rc = 0 if args.lenient_exit else TP_ABANDONED_RC
+
         def abandon():
+            # every rank says where it stands (stderr): the stage of the leg and, if a peer gather is alive, its slot / epoch view
+            try:
+                where = _TP_STATE.get("stage", "?")
+                peer_ = _TP_STATE.get("peer")
+                print(f"[bench rank {rank}] tp_70b leg abandoned after {args.tp_timeout} s at stage '{where}'"
+                      + (f"; peer gather: {peer_.describe_wait()}" if peer_ is not None else "; no peer gather alive"),
+                      file=sys.stderr, flush=True)
+            except Exception as exc:  # noqa: BLE001 (diagnostics must not keep the process alive)
+                print(f"[bench rank {rank}] tp_70b leg abandoned (no state: {exc!r})", file=sys.stderr, flush=True)
             if rank == 0 and not printed[0]:
                 printed[0] = True
                 out["tp_70b"] = {"error": f"abandoned after {args.tp_timeout} s (a rank failed or a collective did not complete); "
                                           "the headline above was measured before this leg"}
                 out["tp_70b_abandoned"] = True   # (top level: a run record can flag it without parsing the leg)
                 print(json.dumps(out), flush=True)
-                print(f"[bench] tp_70b leg ABANDONED after {args.tp_timeout} s; exit code {TP_ABANDONED_RC if args.strict_exit else 0}"
-                      f" (--strict-exit: {TP_ABANDONED_RC})", file=sys.stderr, flush=True)
+                print(f"[bench] tp_70b leg ABANDONED after {args.tp_timeout} s; exit code {fail_rc} (--lenient-exit: 0)", file=sys.stderr, flush=True)
                 if os.environ.get("QPAL_BENCH_HEADLINE_FILE") and os.path.exists(os.environ["QPAL_BENCH_HEADLINE_FILE"]):
                     os.remove(os.environ["QPAL_BENCH_HEADLINE_FILE"])
-            os._exit(TP_ABANDONED_RC if args.strict_exit else 0)
+            os._exit(fail_rc)
 
         park = os.environ.get("QPAL_BENCH_HEADLINE_FILE") if rank == 0 else None
         if park:
@@ -992,8 +1029,11 @@ def main():
         watchdog.start()
         try:
             out["tp_70b"] = tp_leg(qp, torch, dist, args, rank, world, device)
-        except Exception as exc:
+        except Exception as exc:  # the leg raised on this rank: the headline still goes out, the run fails
             out["tp_70b"] = {"error": repr(exc)}
+            out["tp_70b_abandoned"] = True
+            tp_failed[0] = True
+            print(f"[bench rank {rank}] tp_70b leg raised at stage '{_TP_STATE.get('stage', '?')}': {exc!r}", file=sys.stderr, flush=True)
     if rank == 0:
         if world == 1 and not args.no_whole_model and not args.incoherent and n == 1:
             # the reference's own metric (eval/measure_latency.py:236-272 times whole-model generate()): the fused decode step of
@@ -1002,6 +1042,12 @@ def main():
                 out["whole_model_decode"] = whole_model_leg(args)
             except Exception as exc:
                 out["whole_model_decode"] = {"error": repr(exc)}
+        if (world == 1 and not args.no_other_configs and not args.incoherent and n == 1 and args.launch == "multi"
+                and args.workload == "llama3.1-8b_tcomb_6_7" and not args.no_graph):
+            try:
+                out["other_configs"] = other_configs_leg(qp, torch, device, args, main_stream)
+            except Exception as exc:
+                out["other_configs"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1:
             layers = build_model(qp, torch, model_key, qstr, 1, device, distinct_codebooks=args.distinct_codebooks,
                                  packing=args.packing, keep_infos=True)
@@ -1020,6 +1066,73 @@ def main():
             pass
     if watchdog is not None:
         watchdog.cancel()
+    if tp_failed[0] and not args.lenient_exit:
+        sys.stdout.flush()
+        raise SystemExit(TP_ABANDONED_RC)
+
+
+OTHER_CONFIGS = [  # (key, workload, batch): BASELINE.json configs[2], [3] (both published qdicts) and [4] on ONE GPU
+    ("llama3.1-8b_mem3p25", "llama3.1-8b_mem3p25", 1),
+    ("llama3.1-8b_figure1d", "llama3.1-8b_figure1d", 1),
+    ("llama3.1-8b_figure1c", "llama3.1-8b_figure1c", 1),
+    ("llama3.1-70b_tcq_6_bs1", "llama3.1-70b_tcq_6", 1),
+    ("llama3.1-70b_tcq_6_bs16", "llama3.1-70b_tcq_6", 16),
+]
+
+
+def other_configs_leg(qp, torch, device, args, stream):
+    """The other BASELINE configs in the driver-timed line: the same token harness as the headline (multi-job
+    launches, harness-owned pre-zeroed outputs, one HIP graph per token), <= 10 replays each between two HIP events, after the
+    headline's timed region.  value = tokens/s (batch x steps / time); frac = algorithmic bytes per token / time / 8 TB/s."""
+    res, cache = {}, {}
+    steps = max(3, min(args.steps, 10))
+    for key, wl, nb in OTHER_CONFIGS:
+        t_leg = time.perf_counter()
+        try:
+            model_key, qstr = WORKLOADS[wl]
+            nl = args.layers or qp.mem_op.get_layer_info(model_key)["nlayers"]
+            if wl not in cache:
+                cache.clear()  # (one model alive at a time beside the headline's)
+                torch.cuda.empty_cache()
+                torch.manual_seed(1234)
+                cache[wl] = build_model(qp, torch, model_key, qstr, nl, device, packing=args.packing)
+            layers = cache[wl]
+            xs = {}
+            for groups in layers:
+                for mod, k, _ in (u for grp in groups for u in grp):
+                    if k not in xs:
+                        xs[k] = torch.randn(nb, k, device=device).half()
+            token, _ = make_token(qp, torch, layers, xs, nb, device, launch="multi")
+            with torch.cuda.stream(stream):
+                token()
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    token()
+                for _ in range(2):
+                    g.replay()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(steps):
+                    g.replay()
+                e1.record(stream)
+                torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / 1e3 / steps
+            abytes = algorithmic_bytes(qp, layers, nb)
+            nlaunch = sum(len(qp.linear.launch_groups([m for m, _, _ in grp], mixed_kv=nb <= 8)) for groups in layers for grp in groups)
+            res[key] = {"value": nb / t, "unit": "tokens/s", "ms_per_step": t * 1e3, "batch": nb, "steps": steps, "layers": nl,
+                        "frac": abytes / t / 1e9 / HBM_PEAK_GBS, "launches_per_token": nlaunch,
+                        "leg_s": round(time.perf_counter() - t_leg, 1)}
+            del g, token
+        except Exception as exc:  # the headline line must not depend on this leg
+            res[key] = {"error": repr(exc)}
+    cache.clear()
+    torch.cuda.empty_cache()
+    return res
+
+
+_TP_STATE = {}  # where the tp_70b leg stands on this rank (stage text, live PeerGatherer): read by the watchdog's post-mortem
 
 
 def whole_model_leg(args):
@@ -1052,7 +1165,8 @@ def tp_leg(qp, torch, dist, args, rank, world, device):
     as the checked baseline.  value = the faster VALID one."""
     t_leg = time.perf_counter()
 
-    def log(msg):  # progress on stderr (rank 0): where a slow or abandoned leg spent its time
+    def log(msg):  # progress on stderr (rank 0): where a slow or abandoned leg spent its time; every rank remembers its stage
+        _TP_STATE["stage"] = msg
         if rank == 0:
             print(f"[bench tp_70b +{time.perf_counter() - t_leg:6.1f} s] {msg}", file=sys.stderr, flush=True)
 
@@ -1076,10 +1190,12 @@ def tp_leg(qp, torch, dist, args, rank, world, device):
     except Exception as exc:  # (PeerGatherer's set-up collectives have completed or failed on every rank alike)
         err = repr(exc)
     if all_ranks_ok(peer is not None):
-        res["peer_gather"] = {"flag_memory": peer.flag_memory, "validated_against_collective": bool(peer.validate())}
+        res["peer_gather"] = {"flag_memory": peer.flag_memory, "buffer_memory": peer.buffer_memory,
+                              "validated_against_collective": bool(peer.validate())}
     else:
         res["peer_gather"] = {"error": err or "set-up failed on another rank", "validated_against_collective": False}
         peer = None
+    _TP_STATE["peer"] = peer
     log(f"peer gather: {res['peer_gather']}")
     stream = torch.cuda.Stream(device)
 
@@ -1145,6 +1261,7 @@ def tp_leg(qp, torch, dist, args, rank, world, device):
             fig["roofline_frac_per_gpu"] = abytes / (best["ms_per_step"] / 1e3) / 1e9 / HBM_PEAK_GBS
             res[f"bs{nb}"] = fig
     finally:
+        _TP_STATE["peer"] = None
         if peer is not None:
             peer.close()
     return res

@@ -5,7 +5,7 @@
 # so that drift of the box (clock, neighbours) shows up as disagreement between the two passes.
 WL=llama3.1-8b_tcomb_6_7; ARGS=""
 while getopts "w:a:" o; do case $o in w) WL=$OPTARG;; a) ARGS=$OPTARG;; esac; done; shift $((OPTIND-1))
-run() { QPAL_LIB=q-palette_amd/libqpal_hip$1.so timeout -k 10 300 python bench.py --workload $WL --steps 100 --warmup 10 --no-cpu-baseline --no-incoherent-extra $ARGS 2>/dev/null | python -c "
+run() { QPAL_LIB=q-palette_amd/libqpal_hip$1.so timeout -k 10 300 python bench.py --workload $WL --steps 100 --warmup 10 --no-cpu-baseline --no-other-configs --no-incoherent-extra $ARGS 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

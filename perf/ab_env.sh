@@ -3,7 +3,7 @@
 # Every setting runs THREE times, interleaved (drift of the box shows up as disagreement between the passes).
 WL=llama3.1-8b_tcomb_6_7; ARGS=""
 while getopts "w:a:" o; do case $o in w) WL=$OPTARG;; a) ARGS=$OPTARG;; esac; done; shift $((OPTIND-1))
-run() { env $1 timeout -k 10 300 python bench.py --workload $WL --steps 100 --warmup 10 --no-cpu-baseline --no-incoherent-extra --no-whole-model --no-calibration $ARGS 2>/dev/null | python -c "
+run() { env $1 timeout -k 10 300 python bench.py --workload $WL --steps 100 --warmup 10 --no-cpu-baseline --no-incoherent-extra --no-whole-model --no-calibration --no-other-configs $ARGS 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

@@ -2,7 +2,7 @@
 # Same-box A/B of library builds on the headline token (batch 1, multi-job launches):  bash perf/ab_libs.sh <out> <lib suffix ...>
 # ("base" = q-palette_amd/libqpal_hip.so, "x" = libqpal_hip_x.so; three interleaved rounds)
 out=$1; shift; mkdir -p $(dirname $out)
-B="python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-incoherent-extra --no-whole-model --no-calibration"
+B="python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-other-configs --no-incoherent-extra --no-whole-model --no-calibration"
 for r in 1 2 3; do for v in "$@"; do
   lib=$PWD/q-palette_amd/libqpal_hip_$v.so; [ "$v" = base ] && lib=$PWD/q-palette_amd/libqpal_hip.so
   QPAL_LIB=$lib timeout -k 10 300 $B 2>/dev/null | python -c "

@@ -1,7 +1,7 @@
 #!/bin/bash
 # as perf/ab_libs.sh, with the calibration block (decode rate on register-resident words, stream token):  bash perf/ab_libs_calib.sh <out> <lib suffix ...>
 out=$1; shift; mkdir -p $(dirname $out)
-B="python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-incoherent-extra --no-whole-model"
+B="python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-other-configs --no-incoherent-extra --no-whole-model"
 for r in 1 2 3; do for v in "$@"; do
   lib=$PWD/q-palette_amd/libqpal_hip_$v.so; [ "$v" = base ] && lib=$PWD/q-palette_amd/libqpal_hip.so
   QPAL_LIB=$lib timeout -k 10 300 $B 2>/dev/null | python -c "

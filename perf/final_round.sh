@@ -5,7 +5,7 @@ tag=${1:-rXX}; shift; sections=${@:-workloads latency decode bench}; out=gpurun_
 has() { [[ " $sections " == *" $1 "* ]]; }
 if has workloads; then
 rm -f $out/workloads.txt
-B="python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-incoherent-extra --no-kind-breakdown --no-whole-model --no-calibration"
+B="python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-other-configs --no-incoherent-extra --no-kind-breakdown --no-whole-model --no-calibration"
 line() { python -c "
 import json,sys
 for l in sys.stdin:

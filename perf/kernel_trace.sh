@@ -3,7 +3,7 @@
 #   bash perf/kernel_trace.sh <workload> <outfile> [extra bench args]
 wl=$1; out=$GRAFT_REPO_ROOT/$2; shift 2
 d=$(mktemp -d /tmp/kt.XXXX); cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $d -o kt --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline --no-incoherent-extra --no-kind-breakdown --no-whole-model --no-calibration "$@" > $d/bench.json 2> $d/err.txt
+rocprofv3 --kernel-trace --stats -d $d -o kt --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-incoherent-extra --no-kind-breakdown --no-whole-model --no-calibration "$@" > $d/bench.json 2> $d/err.txt
 f=$(find $d -name "*kernel_stats.csv" | head -1)
 python3 - "$f" "$d/bench.json" > $out <<'PY'
 import csv, json, sys

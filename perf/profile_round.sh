@@ -3,7 +3,7 @@
 # kernel-trace stats, PMC traffic and SQ counters in separate rocprofv3 passes (no tracing beside counters), in-kernel stamps.
 tag=${1:-rXX}; out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-incoherent-extra --no-kind-breakdown --no-whole-model --no-calibration"
+B="python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-incoherent-extra --no-kind-breakdown --no-whole-model --no-calibration"
 $B > $out/bench.json 2>/dev/null
 rocprofv3 --kernel-trace --stats -d $out/kt -o kt --output-format csv -- $B > $out/kt_bench.json 2>$out/kt.err
 cp $(find $out/kt -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv 2>/dev/null
@@ -18,5 +18,5 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ
 done
 rm -rf $out/p1 $out/p2 $out/kt
 cd $GRAFT_REPO_ROOT
-QPAL_LIB=q-palette_amd/libqpal_hip_stamps.so python3 bench.py --steps 2 --warmup 1 --layers 2 --no-graph --no-cpu-baseline --no-incoherent-extra --no-kind-breakdown --no-whole-model 2>/dev/null | grep "^\[stamps\]" > $out/inkernel_stamps.txt
+QPAL_LIB=q-palette_amd/libqpal_hip_stamps.so python3 bench.py --steps 2 --warmup 1 --layers 2 --no-graph --no-cpu-baseline --no-other-configs --no-incoherent-extra --no-kind-breakdown --no-whole-model 2>/dev/null | grep "^\[stamps\]" > $out/inkernel_stamps.txt
 ls -la $out

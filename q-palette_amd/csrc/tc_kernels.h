@@ -1003,13 +1003,18 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         // hidden loads from the compiler's own, and the hazard waits the compiler puts between the two typed weight-load branches
         // then wait for the early loads anyway, at points no source change moved.)  Every early value then passes through an
         // (empty) volatile asm, which orders its uses behind the wait.
+        // (The waits themselves are UNCONDITIONAL in a first item — with nothing in flight they cost nothing — so that EVERY control-flow
+        // path from an early load to a use of its register passes one: perf/check_early_loads.py walks the disassembly of every build
+        // for exactly that, tests/test_capi_and_host.py runs it.)
         if constexpr (kRotEarly) {
-            if (FIRST && rot_early) {  // the rotation's inputs / the image's table entries, requested at the wave's first instruction
+            if constexpr (FIRST) {
 #ifdef QPAL_STAMPS
                 if (p.dbg) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                 else
 #endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (FIRST && rot_early) {  // the rotation's inputs / the image's table entries, requested at the wave's first instruction
                 if constexpr (kRotTabEarly) {
 #pragma unroll
                     for (int r = 0; r < kRotTab; r++) {
@@ -1020,12 +1025,14 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
             }
         }
         if constexpr (kRot28Early) {
-            if (FIRST && rot28_early) {
+            if constexpr (FIRST) {
 #ifdef QPAL_STAMPS
                 if (p.dbg) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                 else
 #endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (FIRST && rot28_early) {
                 rot_k28_landed(r28);
 #pragma unroll
                 for (int r = 0; r < C1::CHUNKS / 1024; r++) {
@@ -1035,12 +1042,14 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
             }
         }
         if constexpr (kEarly) {
-            if (FIRST && early) {
+            if constexpr (FIRST) {
 #ifdef QPAL_STAMPS  // (the stamp-0 store above is younger than the early loads and takes its time)
                 if (p.dbg) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                 else
 #endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (FIRST && early) {
 #pragma unroll
                 for (int r = 0; r < XR; r++) asm volatile("" : "+v"(exr[r]));
 #pragma unroll

@@ -43,7 +43,9 @@ class _VQBase(PackedLinearBase):
 
 
 class VQLinearPackTensorCore(_VQBase):
-    """Codes stored in mma-tile order (quant_op.py:101-162); fp32 GEMV output."""
+    """Codes stored in mma-tile order (quant_op.py:101-162).  forward() returns the input's dtype.  `_gemv` (internal) returns fp32 from
+    the tensor-core-order kernel and fp16 from the SIMT-order twin that few-row layers keep (fp32 accumulation in both; which of the
+    two runs depends only on the layer's shape and QPAL_SIMT_TWIN, see _simt_twin)."""
     max_fused_batch = 64
 
     def __init__(self, in_features, out_features, lut_bits, vec_sz=2, bias=False, dtype=torch.half, device=None):
@@ -70,18 +72,53 @@ class VQLinearPackTensorCore(_VQBase):
     # accumulate).  `qweight` stays the reference's buffer: state dicts, get_weight() and the fused multi-job launches are unchanged.
     SIMT_TWIN_MAX_ROWS = 2048
 
-    def _simt_twin(self):
-        tw = getattr(self, "_simt_qweight", None)
-        if tw is not None and tw.device == self.qweight.device:
-            return tw
-        if (self.out_features > self.SIMT_TWIN_MAX_ROWS or not self.qweight.is_cuda or os.environ.get("QPAL_SIMT_TWIN", "1") == "0"
-                or (self.vec_sz == 2 and self.lut_bits < 3) or torch.compiler.is_compiling() or torch.cuda.is_current_stream_capturing()):
+    def _twin_eligible(self):
+        return (self.out_features <= self.SIMT_TWIN_MAX_ROWS and self.qweight.is_cuda and os.environ.get("QPAL_SIMT_TWIN", "1") != "0"
+                and not (self.vec_sz == 2 and self.lut_bits < 3))
+
+    def _twin_key(self):
+        q = self.qweight
+        return (q.data_ptr(), q._version, q.device)
+
+    def prepare(self):
+        """(Re)build the SIMT-order twin of `qweight` now.  Called wherever this package writes the codes (gen_layer_from_info,
+        .to() / .cuda(), load_state_dict); call it yourself after writing `qweight` through a path autograd's version counter
+        does not see (`qweight.data.copy_(...)`).  No-op for layers that keep no twin (many rows, CPU, QPAL_SIMT_TWIN=0)."""
+        object.__setattr__(self, "_simt_qweight", None)  # (not a buffer: never part of the state dict)
+        object.__setattr__(self, "_simt_key", None)
+        if not self._twin_eligible():
             return None
         tw = ops.tc_to_simt(self.qweight, self.out_features, self.in_features, self.lut_bits, self.vec_sz)
-        object.__setattr__(self, "_simt_qweight", tw)  # (not a buffer: never part of the state dict)
+        object.__setattr__(self, "_simt_qweight", tw)
+        object.__setattr__(self, "_simt_key", self._twin_key())
         ops.register_names(["sq_pack_gemm_simt"] if self.vec_sz == 1 else
                            [f"vq_pack_gemm_simt_{bs}_{self.vec_sz}_{self.lut_bits}" for bs in range(1, 9)])
         return tw
+
+    def _simt_twin(self):
+        """The twin iff it matches the codes `qweight` holds NOW: the cache is keyed on (storage address, autograd version, device), so
+        a load_state_dict() / in-place update / move after the first call re-packs instead of decoding stale codes.  While a stream
+        capture or a trace is running a missing / stale twin is not rebuilt (the re-pack is a launch and an allocation): that call
+        takes the tensor-core-order kernel, which reads `qweight` itself."""
+        if not self._twin_eligible():
+            return None
+        tw = getattr(self, "_simt_qweight", None)
+        if tw is not None and getattr(self, "_simt_key", None) == self._twin_key():
+            return tw
+        if torch.compiler.is_compiling() or torch.cuda.is_current_stream_capturing():
+            return None
+        return self.prepare()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        object.__setattr__(self, "_simt_qweight", None)  # the buffers may have moved: re-pack at the next eager call
+        object.__setattr__(self, "_simt_key", None)
+        return out
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        object.__setattr__(self, "_simt_qweight", None)
+        object.__setattr__(self, "_simt_key", None)
 
     def _gemv(self, x, bs):
         m, k = self.out_features, self.in_features
@@ -108,6 +145,8 @@ class VQLinearPackTensorCore(_VQBase):
         layer.lut.data.copy_(info["lut"])
         if info["bias"] is not None:
             layer.bias.data.copy_(info["bias"])
+        if layer.qweight.is_cuda:
+            layer.prepare()
         return layer
 
 

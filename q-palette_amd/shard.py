@@ -111,8 +111,9 @@ class PeerGatherer:
     Memory: the flag blocks are polled by a running kernel while a REMOTE GPU writes them, so they live in fine-grained
     device memory (qpal_peer_alloc kind 1; uncached as second choice) — ordinary hipMalloc memory is only guaranteed coherent
     at kernel boundaries.  `flag_memory` says which kind was obtained ("fine-grained" / "uncached" / "coarse-grained": the
-    last only if the platform refused both, and then `validated` matters all the more).  The gather buffers are consumed
-    after the gather kernel has ended (kernel boundary), so they stay ordinary memory.
+    last only if the platform refused both, and then `validated` matters all the more).  The gather buffers are fine-grained
+    as well (`buffer_memory`; round 5): their visibility to the consumer launch does not rest on what a kernel boundary does
+    to coarse-grained memory that a REMOTE agent wrote.
 
     Call sites: each call inside a token takes the next slot (buffers and flags are never shared between call sites).  A fast
     rank can start token T+1 while a slow peer still runs token T, but it cannot pass the token's LAST call site before that
@@ -152,9 +153,17 @@ class PeerGatherer:
                         lib.qpal_peer_free(ptr)
             raise nat.QpalError("PeerGatherer: no shareable device memory (qpal_peer_alloc / qpal_ipc_export failed)")
 
-        self._bufs_ptr, hb, _ = alloc(nbuf, (0,))
+        # Round 5: the gather buffers are fine-grained too.  Remote GPUs write them over xGMI while kernels of THIS GPU run, and the
+        # consumer reads a slot that the previous token's consumer may have left in this GPU's L2: ordinary (coarse-grained) device
+        # memory is only guaranteed coherent with a remote writer at a SYSTEM-scope acquire, and a kernel boundary inside a
+        # stream / graph is an agent-scope one.  Fine-grained memory takes the question away (remote writes are visible to loads
+        # issued after the flag's system-scope acquire, whatever this GPU cached before); the slices are 2-57 KB, so what the
+        # uncached reads cost is not measurable beside the launch.  `buffer_memory` says which kind was obtained.
+        self._bufs_ptr, hb, bkind = alloc(nbuf, (1, 2, 0))
         self._ws_ptr, hw, kind = alloc(nws, (1, 2, 0))
-        self.flag_memory = {1: "fine-grained", 2: "uncached", 0: "coarse-grained"}[kind]
+        names = {1: "fine-grained", 2: "uncached", 0: "coarse-grained"}
+        self.flag_memory, self.buffer_memory = names[kind], names[bkind]
+        self._calls = 0   # host-side count of gather launches ISSUED (a replayed graph re-runs captured ones without the host)
         everyone = [None] * world
         dist.all_gather_object(everyone, (hb, hw), group=group)
         self.peer_bufs, self.peer_ws = [], []
@@ -230,6 +239,7 @@ class PeerGatherer:
         assert nbytes % 16 == 0 and nbytes <= self.max_bytes and self._next < self.slots
         slot = self._next
         self._next += 1
+        self._calls += 1
         if slot not in self._widths:
             widths = [None] * self.world
             dist.all_gather_object(widths, int(ml), group=self._group)
@@ -256,6 +266,35 @@ class PeerGatherer:
         if len(set(widths)) == 1:
             return out.reshape(1, self.world * ml) if n == 1 else out.permute(1, 0, 2).reshape(n, self.world * ml)
         return torch.cat([out[r, :, :w] for r, w in enumerate(widths)], dim=1)
+
+    def describe_wait(self, timeout_s=2.0):
+        """One line for a post-mortem (bench.py prints it from every rank when it abandons a multi-GPU leg): the host's view (call
+        sites of the current token, launches issued) and — read from the device on a helper thread, given up after `timeout_s`, the
+        card may be wedged — per slot the epoch this rank has reached and the peers whose flag is still behind it."""
+        import threading
+        host = (f"rank {self.rank}/{self.world}: next call site {self._next} of {self.slots} slots, sites in the last token "
+                f"{self._sites_last_token}, gather launches issued by the host {self._calls}")
+        box = {}
+
+        def read():
+            try:
+                w = self.ws.view(torch.int32).view(self.slots, -1).cpu()
+                behind = []
+                for s_ in range(self.slots):
+                    ep = [int(w[s_, 16 + p]) for p in range(self.world)]
+                    late = [p for p in range(self.world) if int(w[s_, p]) - ep[p] < 0]
+                    if late:
+                        behind.append(f"slot {s_}: epoch {max(ep)}, flags behind from ranks {late}")
+                    if int(w[s_, 32]) != 0:
+                        behind.append(f"slot {s_}: a bounded wait gave up at epoch {int(w[s_, 32])}")
+                box["dev"] = "; ".join(behind[:6]) if behind else "no slot is waiting for a peer"
+            except Exception as exc:  # noqa: BLE001 (diagnostics only)
+                box["dev"] = f"device state unreadable ({exc!r})"
+
+        t = threading.Thread(target=read, daemon=True)
+        t.start()
+        t.join(timeout_s)
+        return host + " | device: " + box.get("dev", f"no answer within {timeout_s} s (a kernel is still running or the card is wedged)")
 
     def error(self):
         """!= 0 after a synchronisation: a wait for a peer's flag gave up."""

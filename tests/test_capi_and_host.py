@@ -272,3 +272,44 @@ def test_batches_above_the_fused_batch_do_not_recurse_on_layers_without_a_multi_
         y = layer(torch.zeros(bs, 256).half())
         assert calls == want and tuple(y.shape) == (bs, 256) and y.dtype == torch.float16
         assert float(y[0, 0]) == 1.0 and float(y[-1, 0]) == 2.0  # rows of pass 1, then rows of pass 2
+
+
+def test_early_load_registers_are_untouched_until_their_wait():
+    """the fused GEMV kernels issue their early-staging loads from inline asm, outside the compiler's wait-count
+    bookkeeping, and wait for them by hand — so nothing but the register allocator's choices kept a destination register from being
+    copied, reused or spilled in between.  perf/check_early_loads.py disassembles every fused-GEMV code object of THIS build and
+    walks the control-flow graph from every such load: this test fails the build that breaks the rule."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_check_early", os.path.join(ROOT, "perf", "check_early_loads.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    build = os.path.join(ROOT, "q-palette_amd", "csrc", "build")
+    if not os.path.isdir(build) or not os.path.exists(os.path.join(chk.LLVM, "llvm-objdump")):
+        pytest.skip("no object files of this build / no llvm-objdump (the library was built elsewhere)")
+    r = chk.run(build)
+    assert r["kernels"] >= 150 and r["early_loads"] >= 800, r
+    assert r["violations"] == [], "\n".join(r["violations"][:10])
+    # kernels that spill AND stage early are covered by the same walk (their scratch stores are instructions like any other);
+    # the count is pinned so that a new spilling instantiation is noticed
+    assert len(r["early_with_scratch"]) <= 32, r["early_with_scratch"]
+    # the checker itself: a copy, a reuse and a spill in front of the wait are caught, a wait that covers the load clears it
+    ld = ("global_load_dword", "v10, v2, s[4:5]", 0, None)
+    fetch = ("s_load_dwordx8", "s[24:31], s[12:13], s9 offset:0x78", 8, None)
+    wait0 = ("s_waitcnt", "vmcnt(0)", 12, None)
+    use = ("v_xor_b32_e32", "v11, 0x8000, v10", 16, None)
+    end = ("s_endpgm", "", 20, None)
+    assert chk.check_kernel("k", [ld, fetch, wait0, use, end]) == (1, [])
+    for culprit in (("v_mov_b32_e32", "v12, v10", 4, None), ("v_mov_b32_e32", "v10, v3", 4, None),
+                    ("scratch_store_dword", "off, v10, off offset:4", 4, None)):
+        n, bad = chk.check_kernel("k", [ld, culprit, fetch, wait0, use, end])
+        assert n == 1 and len(bad) == 1 and culprit[0] in bad[0]
+    # a counted wait covers the load only once enough younger operations are behind it
+    ld2 = ("global_load_dword", "v20, v2, s[4:5]", 2, None)
+    wait1 = ("s_waitcnt", "vmcnt(1)", 12, None)
+    assert chk.check_kernel("k", [ld, ld2, fetch, wait1, use, end]) == (2, [])            # v10 is the older of two: vmcnt(1) covers it
+    n, bad = chk.check_kernel("k", [ld2, ld, fetch, wait1, use, end])
+    assert n == 2 and len(bad) == 1                                                      # v10 is the younger: vmcnt(1) does not
+    # and a path AROUND the wait is found
+    br = ("s_cbranch_scc1", "3", 10, 16)
+    n, bad = chk.check_kernel("k", [ld, fetch, br, wait0, use, end])
+    assert n == 1 and len(bad) == 1

@@ -143,6 +143,70 @@ def test_simt_golden(qp, oracle, vec, bits):
         _check_gemv(y.float().cpu().numpy().reshape(n, m), W, x.reshape(n, k), oracle, fp16_out=True)
 
 
+@pytest.mark.parametrize("bits", [2, 4, 5, 8])
+def test_sq_pack_gemm_inplace_simt(qp, oracle, bits):
+    """sq_pack_gemm_inplace_simt (reference: lib/linear/__init__.py:372-378 — pack_gemm into a caller-owned `output`): the op
+    mutates `output` and returns nothing; NaN-filled before the call, every element must come back written and agree with the
+    oracle and, bit for bit, with the allocating twin sq_pack_gemm_simt."""
+    g = _g("simt.npz")
+    m, k = int(g["m"]), int(g["simt_v1_k"])
+    q, idx = g[f"simt_v1_b{bits}_qweight"], g[f"simt_v1_b{bits}_idx"]
+    rng = np.random.default_rng(bits * 11 + 1)
+    lut = rng.standard_normal((1 << bits, 1)).astype(np.float16)
+    W = lut[idx].reshape(m, k)
+    qd, ld = _cuda(q.view(np.int32)), _cuda(lut)
+    inplace, alloc = qp.ops.get_op("sq_pack_gemm_inplace_simt"), qp.ops.get_op("sq_pack_gemm_simt")
+    for n in (1, 3, 8):
+        x = rng.standard_normal((n, 1, k)).astype(np.float16)
+        out = torch.full((n, 1, m), float("nan"), dtype=torch.float16, device="cuda")
+        assert inplace(_cuda(x), qd, ld, out, bits) is None
+        assert not torch.isnan(out).any()
+        _check_gemv(out.float().cpu().numpy().reshape(n, m), W, x.reshape(n, k), oracle, fp16_out=True)
+        assert torch.equal(out, alloc(_cuda(x), qd, ld, bits))
+    with pytest.raises(RuntimeError):
+        inplace(_cuda(rng.standard_normal((1, 1, k)).astype(np.float16)), qd, ld, torch.empty((1, 1, m), dtype=torch.float16, device="cuda"), 9)
+
+
+def test_opcheck_one_op_of_each_family(qp):
+    """torch.library.opcheck over one operator of every family of the ours_lib surface (schema, fake-tensor / meta agreement,
+    mutation annotations, AOT dispatch): what torch.compile relies on when the reference's modules call these names."""
+    from torch.library import opcheck
+    k, m = 256, 64
+    rng = np.random.default_rng(3)
+    x1 = torch.randn(1, k, device="cuda").half()
+    utils = ("test_schema", "test_faketensor", "test_aot_dispatch_static", "test_aot_dispatch_dynamic")
+    # TCQ, single stream and column split
+    for qstr in ("tcq_4_none_0.9", "tcomb_6_7_0.5_none_0.9"):
+        info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=1)
+        layer = qp.make_linear_from_info(qstr, info).cuda()
+        if "tcomb" in qstr:
+            name = f"decompress_gemm_tcq_combt_{m}_1_{k}_{layer.tlut_bits}_{layer.KV[0]}_{layer.KV[1]}"
+            opcheck(qp.ops.get_op(name).default, (layer.trellis1, layer.trellis2, x1, layer.tlut), test_utils=utils)
+        else:
+            name = f"decompress_gemm_tcq_{m}_1_{k}_{layer.tlut_bits}_{layer.KV}"
+            opcheck(qp.ops.get_op(name).default, (layer.trellis, x1, layer.tlut), test_utils=utils)
+            opcheck(qp.ops.get_op(f"decompress_tcq_{layer.tlut_bits}_{layer.KV}").default, (layer.trellis, layer.tlut, m, k), test_utils=utils)
+    # VQ / SQ, tensor-core packing: allocating GEMV and the gemv that mutates `out`
+    info = qp.mem_op.dummy_linear_info(k, m, "ldlq_2_6_none_1.0", seed=2)
+    layer = qp.VQLinearPackTensorCore.gen_layer_from_info(info).cuda()
+    opcheck(qp.ops.get_op(f"decompress_gemm_{m}_1_{k}_6_vq2").default, (layer.qweight, x1, layer.lut), test_utils=utils)
+    out = torch.zeros(m, dtype=torch.float32, device="cuda")
+    opcheck(qp.ops.get_op(f"decompress_gemv_{m}_{k}_6_vq2").default, (layer.qweight, x1, layer.lut, out), test_utils=utils)
+    # SIMT packings: allocating, in-place
+    idx = torch.from_numpy(rng.integers(0, 16, size=(m, k), dtype=np.int64))
+    q = qp.packers.pack_qweight_sq_simt(idx, 4).cuda()
+    lut = torch.randn(16, 1, device="cuda").half()
+    x3 = x1.reshape(1, 1, k)
+    opcheck(qp.ops.get_op("sq_pack_gemm_simt").default, (x3, q, lut, 4), test_utils=utils)
+    opcheck(qp.ops.get_op("sq_pack_gemm_inplace_simt").default, (x3, q, lut, torch.zeros(1, 1, m, dtype=torch.float16, device="cuda"), 4),
+            test_utils=utils)
+    idx = torch.from_numpy(rng.integers(0, 64, size=(m, k // 2), dtype=np.int64))
+    q2 = qp.packers.pack_qweight_vq_simt(idx, 6, 2).cuda()
+    lut2 = torch.randn(64, 2, device="cuda").half()
+    opcheck(qp.ops.get_op("vq_pack_gemm_simt_1_2_6").default, (x3, q2, lut2), test_utils=utils)
+    opcheck(qp.ops.get_op("vq_pack_dequant_simt_2_6").default, (q2, lut2, m, k), test_utils=utils)
+
+
 @pytest.mark.parametrize("vec,bits,m,k", [(1, 2, 8199, 2560), (1, 7, 8199, 2560), (2, 3, 8199, 2560), (2, 9, 8199, 6144),
                                           (4, 6, 8199, 5120), (4, 12, 8199, 4096), (2, 5, 1024, 14336), (4, 8, 4096, 14336),
                                           (1, 4, 1023, 4096)])
@@ -239,6 +303,43 @@ def test_simt_module_loads_tensor_core_file(qp, oracle):
         x = torch.randn(2, k, generator=torch.Generator().manual_seed(5)).half()
         y = layer(x.cuda())
         _check_gemv(y.float().cpu().numpy(), W, x.numpy(), oracle, fp16_out=True)
+
+
+def test_simt_twin_follows_reloaded_codes(qp, oracle):
+    """A few-row VQ / SQ layer in tensor-core packing answers batch <= 8 from a SIMT-order twin of its codes (vq_linear.py).  The twin
+    must follow the codes: forward, then load_state_dict() / an in-place update / a device round trip, then forward again — every
+    answer against the oracle on the codes the layer holds at that moment (round 4 cached the twin of the FIRST codes for good)."""
+    k, m = 4096, 1024
+    for qstr in ("ldlq_1_4_none_1.0", "ldlq_2_8_none_1.0"):
+        infos = [qp.mem_op.dummy_linear_info(k, m, qstr, seed=70 + i) for i in range(3)]
+        Ws = [_oracle_weight(oracle, qstr, info, m, k) for info in infos]
+        assert not np.array_equal(Ws[0], Ws[1])
+        layer = qp.VQLinearPackTensorCore(k, m, infos[0]["lut_bits"], infos[0]["vec_sz"], device="cuda")
+        x = torch.randn(2, k, generator=torch.Generator().manual_seed(5)).half()
+
+        def check(W):
+            y = layer._gemv(x.cuda(), 2)
+            assert y.dtype == torch.float16 and getattr(layer, "_simt_qweight", None) is not None   # the twin answered
+            _check_gemv(y.float().cpu().numpy(), W, x.numpy(), oracle, fp16_out=True)
+            assert np.array_equal(_bits(layer.get_weight()), W.view(np.uint16))
+
+        layer._gemv(x.cuda(), 2)  # (random initial codes: a twin exists before anything is loaded)
+        src = qp.VQLinearPackTensorCore.gen_layer_from_info(infos[0])
+        layer.load_state_dict(src.state_dict())
+        check(Ws[0])
+        with torch.no_grad():
+            layer.qweight.copy_(infos[1]["qweight"].cuda())  # in-place update: the version counter moves
+            layer.lut.copy_(infos[1]["lut"].cuda())
+        check(Ws[1])
+        layer = layer.cpu().cuda()  # a move: new storage
+        check(Ws[1])
+        layer.qweight = infos[2]["qweight"].cuda()  # re-assignment of the buffer
+        layer.lut = infos[2]["lut"].cuda()
+        check(Ws[2])
+        layer.qweight.data.copy_(infos[0]["qweight"].cuda())  # invisible to the version counter: prepare() is the documented call
+        layer.lut.data.copy_(infos[0]["lut"].cuda())
+        layer.prepare()
+        check(Ws[0])
 
 
 def test_graph_capture_and_determinism(qp):
