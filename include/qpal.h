@@ -270,6 +270,20 @@ int qpal_attn_rope_decode(const float *q, const float *k, const float *v, void *
                           const long *pos, const float *inv_freq, int nq, int nkv, int hd, long max_len, float scale,
                           void *ws, long ws_bytes, void *stream);
 
+/* The launch planner of the fused GEMV entry points, on its own (host code, no GPU call; what tests and tools inspect).
+ * A launch of njobs jobs — rows[j] supertile rows (m / 32) of steps1[j] + steps2[j] steps (a step = 128 columns; steps2 = 0: one
+ * stream) — is cut into workgroup-sized pieces: a GROUP of G = 1 << lg_g workgroups (`waves` = 16 or 8 waves each) owns rg
+ * consecutive rows; its work, laid out as a tape (row 0 stream 1, row 0 stream 2, row 1 ...), is cut into G equal ranges and every
+ * range into one piece per wave.  flags[j]: bit 0 the output is zeroed, bit 1 the job accumulates, bit 2 SwiGLU epilogue;
+ * shared_staging: the jobs read one x / codebook (groups may then run across job boundaries).  out (ints):
+ *   [0] grid  [1] items  [2] geometry classes  [3] items of class 0  [4] groups span jobs  [5] class-1 job mask  [6] M  [7] W
+ *   then per class c < 2: lg_g, rg, M * W entries (a, b) — a: bits 0..7 row inside the group, 8 stream 2, 9 lead of its row's run,
+ *   10 row shared with another workgroup, 11..15 waves in the run, 16 has steps, 17 SwiGLU lead; b: first step | steps << 16 —
+ *   then per job: class, first virtual row, end of its virtual rows, 2 if its output must start at zero (shared rows) else 1.
+ * out_len >= 8 + 2 * (2 + 2 * M * W) + 4 * njobs (M = 4, W = 16).                                                              */
+int qpal_plan_gemv(const int *rows, const int *steps1, const int *steps2, const int *flags, int njobs, int waves, int shared_staging,
+                   int *out, int out_len);
+
 /* 1 if the GEMV entry points can apply the rotation themselves (x_had): k in {2048, 4096} at batch 1 (the
  * decode case); 0 otherwise (then call qpal_hadamard first). */
 int qpal_can_fuse_rotation(int n, int k);

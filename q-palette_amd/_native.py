@@ -46,6 +46,7 @@ _SIGNATURES = {
     "qpal_lut_simt_gemv": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "qpal_lut_simt_dequant": [_P, _P, _P, _I, _I, _I, _I, _P],
     "qpal_tc_to_simt": [_P, _P, _I, _I, _I, _I, _P],
+    "qpal_plan_gemv": [ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _I, _I, ctypes.POINTER(_I), _I],
     "qpal_can_fuse_rotation": [_I, _I],
     "qpal_can_fuse_rotation_k": [_I, _I, _I],
     "qpal_pack_tcq": [_P, _P, _I, _I, _I],

@@ -8,7 +8,6 @@ int launch_lut_tc_gemv(const TcMultiParams &p, int bits, int vec, int nbg, int g
 int launch_lut_tc_gemv_wide(const TcMultiParams &p, int bits, int vec, int nbg, int grid, hipStream_t stream);
 int launch_lut_tc_gemm(const TcMultiParams &p, int bits, int vec, int nbg, int grid, hipStream_t stream);
 int launch_lut_tc_gemv_rot28(const TcMultiParams &p, int bits, int vec, int grid, hipStream_t stream);
-int launch_lut_tc_gemv_pair(const TcMultiParams &p, int bits, int vec, int grid, hipStream_t stream);
 int launch_lut_tc_gemv_rot(const TcMultiParams &p, int bits, int vec, int grid, hipStream_t stream);
 int launch_lut_tc_dequant(const TcParams &p, int bits, int vec, int grid, hipStream_t stream);
 int launch_simt_gemv(const SimtParams &p, int bits, int vec, int nb, const SimtGeometry &g, hipStream_t stream);

@@ -113,120 +113,317 @@ int set_rotation(TcParams &p, int x_had, const void *x_su, float x_post, int n, 
 
 int nb_of(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : 8; }
 
-// Launch geometry of the fused GEMV.  16 waves per workgroup, one workgroup per CU.  A supertile row
-// (32 output rows) has st1 + st2 steps, cut into chunks (never straddling the two streams of a combt layer)
-// for `wpr` waves (power of two <= 16) of `sk` workgroups.
+// Launch geometry of the fused GEMV (round 5: "tape cut").  16 (8) waves per workgroup, one workgroup per CU.
 //
-// plan_launch() picks ONE wpr for all jobs of a launch: the largest that still fits the launch into a single
-// round of <= 256 workgroups (fewer, longer-running workgroups: the codebook image, x staging and the
-// first-byte latency are paid once, no cold restart between items).  Split-K over workgroups (sk > 1:
-// zeroed output + float atomics) is used when the launch would leave >= half of the CUs idle and the waves
-// have enough steps to share; it costs a memset node unless the caller pre-zeroed the output.
-// experiment knobs (perf/ scripts only): QPAL_FORCE_SK=<n>, QPAL_FORCE_WPR=<log2>
+// A GROUP of G workgroups (G = 1, 2, 4) owns RG consecutive supertile rows (32 output rows each).  The group's work is a TAPE:
+// row 0 stream 1, row 0 stream 2, row 1 stream 1, ... — RG * (st1 + st2) steps — cut into G equal member ranges, and a member's
+// range into one piece per wave (a wave never straddles a row or a stream of a column-split layer; pieces of one row are
+// consecutive waves, so the cross-wave reduction sums a run of waves).  A row whose steps fall into two members is SHARED: both
+// add their partial sums with float atomics into an output the caller declared zeroed (or accumulates onto) — at most two adders
+// per element when a member range holds at least one row's steps, so the sums stay order-independent.  Every earlier mode is a
+// tape cut: whole rows (G = 1), split-K (RG = 1), pair mode (G = 2, RG = 2 R - S) — and so is what they could not express, e.g.
+// q|k|v of Llama-8B (192 rows of 32 steps) on 256 workgroups: G = 4, RG = 3, 24 steps per workgroup, 6 per SIMD instead of 8.
+// The planner enumerates (G, RG) per geometry class (jobs of one launch differ in geometry at most by single- vs two-stream),
+// builds the per-wave table of every candidate and keeps the cheapest: rounds of <= 256 workgroups x the busiest SIMD's steps
+// (waves w, w + 4, w + 8, w + 12 of a workgroup share a SIMD).  The kernel reads ITS table entry — 8 bytes per (member, wave) —
+// with the first kernel-argument round trip: no chunk arithmetic is left in its prologue.
+// experiment knobs (perf/ scripts only): QPAL_FORCE_G=<1|2|4>, QPAL_FORCE_RG=<rows per group>, QPAL_SHARE=0 (QPAL_PAIR=0): no
+// row sharing on zeroed outputs beyond what the memset rule below allows
 static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
 }
 
-void set_chunks(TcParams &p, int log2_wpr, int sk, int waves = 16) {
-    const int st1 = p.st1, st2 = p.st2, st = st1 + st2;
-    const int nchunk = (1 << log2_wpr) * sk;
-    int nc1 = nchunk;
-    if (st2 > 0) {
-        nc1 = (int)(((long)nchunk * st1 + st / 2) / st);
-        if (nc1 < 1) nc1 = 1;
-        if (nc1 > nchunk - 1) nc1 = nchunk - 1;
+struct TapePlan {
+    LaunchPlan lp;
+    int cost;      // steps of the busiest SIMD of any member
+    bool shared;   // some row is summed by two workgroups
+    bool ok;
+};
+
+// table of one candidate: waves W (16 or 8), group of (1 << lg_g) workgroups x rg rows, st1 + st2 steps per row
+TapePlan tape_plan(int lg_g, int rg, int st1, int st2, int W) {
+    TapePlan tp{};
+    const int G = 1 << lg_g, st = st1 + st2;
+    tp.lp.lg_g = lg_g;
+    tp.lp.rg = rg;
+    const long T = (long)rg * st;
+    if (st <= 0 || rg < 1 || rg > 255 || T < G) return tp;
+    struct Piece { int row, stream, s0, len; };
+    for (int m = 0; m < G; m++) {
+        const long t0 = T * m / G, t1 = T * (m + 1) / G;
+        Piece pc[kPlanWaves];
+        int np = 0;
+        for (int r = (int)(t0 / st); r < rg && (long)r * st < t1; r++)
+            for (int sidx = 0; sidx < 2; sidx++) {
+                const long seg0 = (long)r * st + (sidx ? st1 : 0), seg1 = seg0 + (sidx ? st2 : st1);
+                const long a = seg0 > t0 ? seg0 : t0, b = seg1 < t1 ? seg1 : t1;
+                if (b <= a) continue;
+                if (np == W) return tp;  // more pieces than waves
+                pc[np++] = Piece{r, sidx, (int)(a - seg0), (int)(b - a)};
+            }
+        // Waves per piece.  What counts is the busiest SIMD (waves w, w + 4, ... share one), not the longest wave: gate | up of
+        // Llama-8B — a member holds three whole rows and half of a fourth, seven pieces of 16 steps — is balanced by 2 waves x 8
+        // steps on the whole pieces and 4 x 4 on the half row (28 steps on every SIMD), not by 7 steps everywhere (21 waves).
+        // Try every quantum q: ceil(len / q) waves per piece, the waves left over given to the piece(s) with the longest waves or
+        // all to one piece — and keep the assignment whose busiest SIMD is least loaded.
+        const long L = t1 - t0;
+        int best_n[kPlanWaves] = {0}, best_cost = 1 << 30, best_long = 1 << 30;
+        const int q0 = (int)((L + W - 1) / W);
+        auto consider = [&](const int *nw) {
+            int simd[4] = {0, 0, 0, 0}, w = 0, longest = 0;
+            for (int i = 0; i < np; i++)
+                for (int part = 0; part < nw[i]; part++, w++) {
+                    const int ns = pc[i].len / nw[i] + (part < pc[i].len % nw[i] ? 1 : 0);
+                    simd[w & 3] += ns;
+                    if (ns > longest) longest = ns;
+                }
+            int c = simd[0];
+            for (int sd = 1; sd < 4; sd++) c = simd[sd] > c ? simd[sd] : c;
+            if (c < best_cost || (c == best_cost && longest < best_long)) {
+                best_cost = c;
+                best_long = longest;
+                for (int i = 0; i < np; i++) best_n[i] = nw[i];
+            }
+        };
+        for (int q = q0 > 0 ? q0 : 1; q <= 4 * q0 + 4; q++) {
+            int nw[kPlanWaves], used = 0;
+            for (int i = 0; i < np; i++) {
+                nw[i] = (pc[i].len + q - 1) / q;
+                used += nw[i];
+            }
+            if (used > W) continue;
+            consider(nw);
+            const int spare = W - used;
+            if (spare == 0) continue;
+            {   // spare waves, one at a time, to the piece with the longest waves
+                int g[kPlanWaves];
+                for (int i = 0; i < np; i++) g[i] = nw[i];
+                for (int k = 0; k < spare; k++) {
+                    int at = -1, worst = 0;
+                    for (int i = 0; i < np; i++) {
+                        const int per = (pc[i].len + g[i] - 1) / g[i];
+                        if (g[i] < pc[i].len && per > worst) { worst = per; at = i; }
+                    }
+                    if (at < 0) break;
+                    g[at]++;
+                }
+                consider(g);
+            }
+            for (int t = 0; t < np; t++) {  // ... or all to one piece
+                int g[kPlanWaves];
+                for (int i = 0; i < np; i++) g[i] = nw[i];
+                g[t] = g[t] + spare < pc[t].len ? g[t] + spare : pc[t].len;
+                consider(g);
+            }
+        }
+        if (best_cost == 1 << 30) return tp;
+        int wave = 0;
+        for (int i = 0; i < np; i++) {
+            int s0 = pc[i].s0;
+            for (int part = 0; part < best_n[i]; part++, wave++) {
+                const int ns = pc[i].len / best_n[i] + (part < pc[i].len % best_n[i] ? 1 : 0);
+                if (ns > 0xffff || s0 > 0xffff) return tp;
+                WaveEnt &e = tp.lp.w[m][wave];
+                e.a = (uint32_t)pc[i].row | ((uint32_t)pc[i].stream << 8) | (1u << 16);
+                e.b = (uint32_t)s0 | ((uint32_t)ns << 16);
+                s0 += ns;
+            }
+        }
+        // runs: consecutive waves of one row; the first is the run's lead and knows its length
+        for (int w0 = 0; w0 < wave;) {
+            int w1 = w0 + 1;
+            while (w1 < wave && (tp.lp.w[m][w1].a & 255u) == (tp.lp.w[m][w0].a & 255u)) w1++;
+            tp.lp.w[m][w0].a |= (1u << 9) | ((uint32_t)(w1 - w0) << 11);
+            w0 = w1;
+        }
+        // busiest SIMD of this member
+        const int per = W / 4;
+        for (int sd = 0; sd < 4; sd++) {
+            int c = 0;
+            for (int q = 0; q < per; q++) c += (int)(tp.lp.w[m][sd + 4 * q].b >> 16);
+            if (c > tp.cost) tp.cost = c;
+        }
     }
-    const int rows_per_wg = waves >> log2_wpr;
-    p.log2_wpr = log2_wpr;
-    p.sk = sk;
-    p.nc1 = nc1;
-    p.base1 = st1 / nc1;
-    p.rem1 = st1 % nc1;
-    p.base2 = st2 > 0 ? st2 / (nchunk - nc1) : 0;
-    p.rem2 = st2 > 0 ? st2 % (nchunk - nc1) : 0;
-    p.nitems = ((p.nrows + rows_per_wg - 1) / rows_per_wg) * sk;
+    // shared rows: a row whose steps lie in two member ranges
+    for (int r = 0; r < rg; r++) {
+        int owners = 0;
+        for (int m = 0; m < G; m++) {
+            bool has = false;
+            for (int w = 0; w < W; w++) has = has || ((tp.lp.w[m][w].a >> 16 & 1u) && (int)(tp.lp.w[m][w].a & 255u) == r);
+            owners += has;
+        }
+        if (owners > 2) return tp;  // at most two adders per output element: (0 + a) + b == (0 + b) + a, results stay reproducible to the bit
+        if (owners > 1) {
+            tp.shared = true;
+            for (int m = 0; m < G; m++)
+                for (int w = 0; w < W; w++)
+                    if ((tp.lp.w[m][w].a >> 16 & 1u) && (int)(tp.lp.w[m][w].a & 255u) == r) tp.lp.w[m][w].a |= 1u << 10;
+        }
+    }
+    tp.ok = true;
+    return tp;
 }
 
-int items_at(const TcMultiParams &mp, int log2_wpr, int waves = 16) {
-    const int rows_per_wg = waves >> log2_wpr;
-    int items = 0;
-    for (int j = 0; j < mp.njobs; j++) items += (mp.job[j].nrows + rows_per_wg - 1) / rows_per_wg;
-    return items;
-}
-
-// out_zeroed[j]: the caller pre-zeroed job j's output (split-K is then free of a memset node)
-void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves = 16, bool allow_pair = false) {
-    static const int force_sk = env_int("QPAL_FORCE_SK", 0);
-    static const int force_wpr = env_int("QPAL_FORCE_WPR", -1);
-    int min_st = 1 << 30;
-    bool two = false;
+// may the groups of a class run across job boundaries?  Only where the jobs agree on everything a workgroup shares (a workgroup
+// stages x and the codebook image ONCE) and no job needs whole row pairs (SwiGLU epilogue)
+bool jobs_share_staging(const TcMultiParams &mp) {
+    const TcParams &a = mp.job[0];
     for (int j = 0; j < mp.njobs; j++) {
-        const int st = mp.job[j].st1 + mp.job[j].st2;
-        if (st < min_st) min_st = st;
-        two = two || mp.job[j].st2 > 0;
+        const TcParams &b = mp.job[j];
+        if (b.x != a.x || b.tab != a.tab || b.n != a.n || b.k != a.k || b.x_lds != a.x_lds || b.x_rot != a.x_rot || b.x_su != a.x_su ||
+            b.x_rms_w != a.x_rms_w || b.x_src_f32 != a.x_src_f32 || b.x_rms_eps != a.x_rms_eps || b.x_hadk != a.x_hadk ||
+            b.x_pre != a.x_pre || b.x_post != a.x_post || b.act_out || b.nsc1 != a.nsc1 || b.nsc2 != a.nsc2 || b.col2 != a.col2)
+            return false;
     }
-    const int log2w = waves == 16 ? 4 : 3;
-    int log2_wpr = log2w;
+    return true;
+}
+
+// virtual rows of class c under a candidate: jobs padded to whole groups, or — `span` — packed back to back
+int class_rows(const TcMultiParams &mp, int c, int rg, bool span) {
+    int rows = 0;
+    for (int j = 0; j < mp.njobs; j++)
+        if (mp.job[j].cls == c) rows += span ? mp.job[j].nrows : (mp.job[j].nrows + rg - 1) / rg * rg;
+    return rows;
+}
+
+// out_zeroed[j]: the caller pre-zeroed job j's output (row sharing is then free of a memset node); nullptr: nobody did
+void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves = 16) {
+    static const int force_g = env_int("QPAL_FORCE_G", 0);
+    static const int force_rg = env_int("QPAL_FORCE_RG", 0);
+    static const int share_on = env_int("QPAL_SHARE", env_int("QPAL_PAIR", 1));
+    static const int span_on = env_int("QPAL_SPAN", 1);
     const int cap = round_capacity(waves);
-    while (log2_wpr > 0 && items_at(mp, log2_wpr, waves) > cap) log2_wpr--;
-    while (log2_wpr > 0 && (1 << log2_wpr) > min_st) log2_wpr--;   // no more waves per row than steps
-    if (two && log2_wpr == 0) log2_wpr = 1;                         // a combt row needs >= 2 chunks
-    bool pairs = false;  // a SwiGLU-epilogue job: two supertile rows (up, gate) per workgroup at least, no split-K
-    for (int j = 0; j < mp.njobs; j++) pairs = pairs || mp.job[j].act_out != nullptr;
-    if (pairs && log2_wpr == log2w) log2_wpr = log2w - 1;
-    if (force_wpr >= 0 && force_wpr <= log2w) log2_wpr = force_wpr;
-    const int items = items_at(mp, log2_wpr, waves);
+    // geometry classes: (st1, st2) — at most two per launch (the entry points split a launch that has more)
+    int ncls = 0, cst1[2] = {0, 0}, cst2[2] = {0, 0};
     for (int j = 0; j < mp.njobs; j++) {
         TcParams &p = mp.job[j];
-        int sk = 1;
-        const int per_wave = (p.st1 + p.st2 + (1 << log2_wpr) - 1) >> log2_wpr;
-        if (items * 2 <= cap && log2_wpr == log2w && !pairs) {
-            // idle CUs: share each row's K range between workgroups if the waves have steps to give away
-            const int want = cap / items;
-            // a memset node costs ~3 us; an accumulating job needs none (its atomics add onto the live output)
-            const int min_steps = ((out_zeroed && out_zeroed[j]) || p.accumulate) ? 2 : 6;
-            while (sk * 2 <= want && per_wave / (sk * 2) * 2 >= min_steps) sk *= 2;
+        int c = 0;
+        while (c < ncls && (cst1[c] != p.st1 || cst2[c] != p.st2)) c++;
+        if (c == ncls) {
+            if (ncls == 2) c = 1;  // (never reached through the entry points: gemv_classes_ok)
+            else { cst1[c] = p.st1; cst2[c] = p.st2; ncls++; }
         }
-        if (force_sk > 0 && (force_sk & (force_sk - 1)) == 0) sk = force_sk;  // (the kernel splits items by shift and mask)
-        set_chunks(p, log2_wpr, sk, waves);
+        p.cls = c;
     }
-    // Pair mode (TcParams::pair): 4 or 2 rows per workgroup, nothing split, every output zeroed (or accumulated onto) and the
-    // launch still one round: two workgroups share the last S of their rows — 2 R - S rows per pair instead of 2 R, every SIMD
-    // with 3.5 / 4 (4, 2 or 1 waves per row) or 3 / 4 (8 waves per row) of the steps.  QPAL_PAIR=0 switches it off (A/B).
-    static const int pair_on = env_int("QPAL_PAIR", 1);
-    const int R = waves >> log2_wpr;
-    const int pair_rows = 2 * R - pair_shared_slots(log2_wpr);  // rows of a workgroup pair
-    bool pair = allow_pair && pair_on && waves == 16 && R >= 2 && !pairs && force_sk <= 0 && out_zeroed != nullptr;
-    int pair_items = 0;
-    for (int j = 0; j < mp.njobs && pair; j++) {
+    // what the jobs allow: sharing a row needs a zeroed (or accumulated-onto) output — or a memset node (~3 us: worth it only for
+    // a large gain); the SwiGLU epilogue needs both rows of an up / gate pair whole inside one workgroup, in runs of equal length
+    bool free_share = share_on != 0, swiglu = false;
+    int min_rows = 1 << 30;
+    for (int j = 0; j < mp.njobs; j++) {
         const TcParams &p = mp.job[j];
-        pair = p.sk == 1 && (out_zeroed[j] || p.accumulate) && p.rem1 == 0 && p.rem2 == 0 && p.base1 >= 2 && (p.base1 & 1) == 0 &&
-               (p.base2 & 1) == 0 && (p.st2 == 0 || p.base2 >= 2);
-        pair_items += 2 * ((p.nrows + pair_rows - 1) / pair_rows);
+        if (!((out_zeroed && out_zeroed[j]) || p.accumulate)) free_share = false;
+        swiglu = swiglu || p.act_out != nullptr;
+        if (p.nrows < min_rows) min_rows = p.nrows;
     }
-    if (pair && pair_items <= cap && pair_items > items) {
+    const bool may_span = span_on && ncls == 1 && mp.njobs > 1 && jobs_share_staging(mp);
+    constexpr int kMemsetCost = 10;  // a memset node in steps of the busiest SIMD (~3 us / 0.3 us)
+    constexpr int kRoundCost = 4;    // a workgroup's fixed cost per item, in steps
+    // candidates per class
+    struct Cand { TapePlan tp; int lg_g, rg; };
+    static thread_local Cand cands[2][3 * 64];
+    int ncand[2] = {0, 0};
+    for (int c = 0; c < ncls; c++)
+        for (int lg = 0; lg <= 2; lg++) {
+            if (force_g > 0 && (1 << lg) != force_g) continue;
+            if (swiglu && lg != 0) continue;
+            for (int rg = 1; rg <= 16 << lg && rg <= 64; rg++) {
+                if (force_rg > 0 && rg != force_rg) continue;
+                if (swiglu && (rg & (rg - 1) || rg < 2 || rg > waves)) continue;
+                TapePlan tp = tape_plan(lg, rg, cst1[c], cst2[c], waves);
+                if (!tp.ok) continue;
+                if (tp.shared && swiglu) continue;
+                cands[c][ncand[c]++] = Cand{tp, lg, rg};
+            }
+        }
+    // cheapest combination: rounds x (busiest SIMD over the classes) [+ memset]; ties: no sharing, fewer workgroups per group,
+    // more workgroups inside the round (the largest number of waves per row that still fits ONE round: the rule of rounds 1-4)
+    long best = -1;
+    int bi[2] = {0, 0};
+    bool bspan = false;
+    for (int i0 = 0; i0 < ncand[0]; i0++)
+        for (int i1 = 0; i1 < (ncls > 1 ? ncand[1] : 1); i1++) {
+            const Cand *cc[2] = {&cands[0][i0], ncls > 1 ? &cands[1][i1] : nullptr};
+            // (a group reaches into the next job at most once: every job must hold a group's rows)
+            const bool span = may_span && min_rows >= cc[0]->rg;
+            int items = 0, cost = 0;
+            bool shared = false;
+            for (int c = 0; c < ncls; c++) {
+                items += (class_rows(mp, c, cc[c]->rg, span) + cc[c]->rg - 1) / cc[c]->rg << cc[c]->lg_g;
+                if (cc[c]->tp.cost > cost) cost = cc[c]->tp.cost;
+                shared = shared || cc[c]->tp.shared;
+            }
+            const int rounds = (items + cap - 1) / cap;
+            // (every round pays a workgroup's prologue again: image and x staged, two barriers — about four steps' worth)
+            long score = (long)rounds * (cost + kRoundCost) + (shared && !free_share ? kMemsetCost : 0);
+            score = score * 4 + (shared ? 1 : 0);
+            score = score * 8 + cc[0]->lg_g + (cc[1] ? cc[1]->lg_g : 0);
+            score = score * 1024 + (1023 - (items < 1023 ? items : 1023));
+            if (best < 0 || score < best) {
+                best = score;
+                bi[0] = i0;
+                bi[1] = i1;
+                bspan = span;
+            }
+        }
+    // the launch's table
+    mp.ncls = ncls;
+    mp.span = bspan ? 1 : 0;
+    mp.cls_mask = 0;
+    int items_c[2] = {0, 0};
+    for (int c = 0; c < ncls; c++) {
+        const Cand &cd = cands[c][bi[c]];
+        mp.plan[c] = cd.tp.lp;
+        int vrow = 0;
         for (int j = 0; j < mp.njobs; j++) {
             TcParams &p = mp.job[j];
-            p.sk = -1;
-            p.nitems = 2 * ((p.nrows + pair_rows - 1) / pair_rows);
+            if (p.cls != c) continue;
+            if (c) mp.cls_mask |= 1 << j;
+            p.vrow0 = vrow;
+            vrow += bspan ? p.nrows : (p.nrows + cd.rg - 1) / cd.rg * cd.rg;
+            mp.row_end[j] = vrow;
+            p.sk = cd.tp.shared ? 2 : 1;  // (> 1: the output must start at zero — zero_split_jobs() adds the memset the caller did not)
+            p.nitems = 0;
+            if (p.act_out) {              // the lead wave of an up row also finishes the gate row behind it
+                for (int w = 0; w < waves; w++) {
+                    WaveEnt &e = mp.plan[c].w[0][w];
+                    if ((e.a >> 9 & 1u) && !((e.a & 255u) & 1u)) e.a |= 1u << 17;
+                }
+            }
         }
+        items_c[c] = (vrow + cd.rg - 1) / cd.rg << cd.lg_g;
     }
-    int total = 0;
-    for (int j = 0; j < kMaxJobs; j++) {
-        if (j < mp.njobs) total += mp.job[j].nitems;
-        mp.item_end[j] = total;
-    }
-    mp.total_items = total;
-    grid = total < cap ? total : cap;
+    for (int j = mp.njobs; j < kMaxJobs; j++) mp.row_end[j] = 0x7fffffff;
+    mp.items0 = items_c[0];
+    mp.total_items = items_c[0] + items_c[1];
+    for (int j = 0; j < kMaxJobs; j++) mp.item_end[j] = mp.total_items;
+    grid = mp.total_items < cap ? mp.total_items : cap;
     static const int plan_log = env_int("QPAL_PLAN_LOG", 0);  // one line per planned GEMV launch on stderr (tests, debugging)
     if (plan_log) {
-        fprintf(stderr, "[qpal plan] gemv: %d jobs, grid %d, waves per row %d:", mp.njobs, grid, 1 << log2_wpr);
-        for (int j = 0; j < mp.njobs; j++)
-            fprintf(stderr, " [rows %d steps %d+%d %s items %d]", mp.job[j].nrows, mp.job[j].st1, mp.job[j].st2,
-                    mp.job[j].sk < 0 ? "pair" : mp.job[j].sk > 1 ? "split-K" : "whole rows", mp.job[j].nitems);
+        fprintf(stderr, "[qpal plan] gemv: %d jobs, grid %d%s:", mp.njobs, grid, bspan ? ", groups span jobs" : "");
+        for (int j = 0; j < mp.njobs; j++) {
+            const Cand &cd = cands[mp.job[j].cls][bi[mp.job[j].cls]];
+            fprintf(stderr, " [rows %d steps %d+%d groups of %d x %d rows, %s, busiest SIMD %d steps]", mp.job[j].nrows, mp.job[j].st1,
+                    mp.job[j].st2, 1 << cd.lg_g, cd.rg, cd.tp.shared ? "shared rows" : "whole rows", cd.tp.cost);
+        }
         fprintf(stderr, "\n");
     }
+}
+
+// one GEMV launch holds at most two geometry classes (single- and two-stream jobs of an any-KV launch, say)
+bool gemv_classes_ok(const TcMultiParams &mp) {
+    int ncls = 0, a1[2], a2[2];
+    for (int j = 0; j < mp.njobs; j++) {
+        int c = 0;
+        while (c < ncls && (a1[c] != mp.job[j].st1 || a2[c] != mp.job[j].st2)) c++;
+        if (c == ncls) {
+            if (ncls == 2) return false;
+            a1[c] = mp.job[j].st1;
+            a2[c] = mp.job[j].st2;
+            ncls++;
+        }
+    }
+    return true;
 }
 
 // Geometry of the lockstep skinny-GEMM kernel (tc_gemm.h, batch > 8): a workgroup = 8 waves = 8 supertile rows that walk one K
@@ -477,6 +674,27 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
     if (split == QPAL_SPLIT_ROWS) return QPAL_E_PARAM;  // the two row halves use different codecs: one call each
     if (n < 1 || n > kMaxBatch) return QPAL_E_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    {   // a launch holds at most two row geometries (k, single / two streams): more -> one launch per geometry
+        long keys[kMaxJobs];
+        int nkeys = 0;
+        for (int j = 0; j < njobs; j++) {
+            const long key = (long)jobs[j].k * 2 + ((split == QPAL_SPLIT_COLS || (jobs[j].kv && jobs[j].kv2 && jobs[j].c2)) ? 1 : 0);
+            int i = 0;
+            while (i < nkeys && keys[i] != key) i++;
+            if (i == nkeys) keys[nkeys++] = key;
+        }
+        if (nkeys > 2) {
+            for (int i = 0; i < nkeys; i++) {
+                qpal_tcq_job sub[kMaxJobs];
+                int ns = 0;
+                for (int j = 0; j < njobs; j++)
+                    if ((long)jobs[j].k * 2 + ((split == QPAL_SPLIT_COLS || (jobs[j].kv && jobs[j].kv2 && jobs[j].c2)) ? 1 : 0) == keys[i]) sub[ns++] = jobs[j];
+                int rc = qpal_tcq_gemv_multi(sub, ns, n, S, KV1, KV2, split, i == 0 ? prezero : nullptr, i == 0 ? prezero_bytes : 0, stream);
+                if (rc) return rc;
+            }
+            return QPAL_OK;
+        }
+    }
     TcMultiParams mp{};
     mp.njobs = njobs;
     int zeroed[kMaxJobs] = {0};
@@ -549,14 +767,12 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         if (rc) return rc;
         return launch_tcq_gemm(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, nbg_of(rows), grid, s);
     }
-    bool plain = nbg == 1;  // pair mode: the plain TCQ kernels of one batch group have a pair-aware twin (tcq_gemv_pair.hip; any-KV: tcq_gemv_any.hip)
-    for (int j = 0; j < njobs; j++) plain = plain && !mp.job[j].x_rot;
-    plan_launch(mp, zeroed, grid, waves_of(nbg), plain);
+    plan_launch(mp, zeroed, grid, waves_of(nbg));
     for (int j = 0; j < njobs; j++) {
         ms[j] = jobs[j].m;
         zeroed[j] = jobs[j].out_zeroed;
-        // the SwiGLU epilogue pairs two supertile rows of one workgroup and has no split-K form
-        if (mp.job[j].act_out && (mp.job[j].sk != 1 || (waves_of(nbg) >> mp.job[j].log2_wpr) < 2)) return QPAL_E_SHAPE;
+        // the SwiGLU epilogue pairs two supertile rows of one workgroup and has no shared-row form (the planner keeps to that)
+        if (mp.job[j].act_out && (mp.job[j].sk != 1 || mp.plan[mp.job[j].cls].rg < 2)) return QPAL_E_SHAPE;
     }
     {
         int rc = zero_split_jobs(mp, ms, zeroed, s);
@@ -640,6 +856,25 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
     if (njobs < 1 || njobs > kMaxJobs) return QPAL_E_SHAPE;
     if (prezero_bytes < 0 || prezero_bytes % 16 || (prezero_bytes && (!prezero || !aligned(prezero, 16)))) return QPAL_E_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    {   // a launch holds at most two row geometries (here: k): more -> one launch per k
+        int keys[kMaxJobs], nkeys = 0;
+        for (int j = 0; j < njobs; j++) {
+            int i = 0;
+            while (i < nkeys && keys[i] != jobs[j].k) i++;
+            if (i == nkeys) keys[nkeys++] = jobs[j].k;
+        }
+        if (nkeys > 2) {
+            for (int i = 0; i < nkeys; i++) {
+                qpal_lut_job sub[kMaxJobs];
+                int ns = 0;
+                for (int j = 0; j < njobs; j++)
+                    if (jobs[j].k == keys[i]) sub[ns++] = jobs[j];
+                int rc = qpal_lut_tc_gemv_multi(sub, ns, n, bits, vec, i == 0 ? prezero : nullptr, i == 0 ? prezero_bytes : 0, stream);
+                if (rc) return rc;
+            }
+            return QPAL_OK;
+        }
+    }
     TcMultiParams mp{};
     mp.njobs = njobs;
     int zeroed[kMaxJobs] = {0};
@@ -688,13 +923,11 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
         if (rc) return rc;
         return launch_lut_tc_gemm(mp, bits, vec, nbg_of(rows), grid, s);
     }
-    bool plain = nbg == 1;  // pair mode: lut_gemv_pair.hip
-    for (int j = 0; j < njobs; j++) plain = plain && !mp.job[j].x_rot;
-    plan_launch(mp, zeroed, grid, waves_of(nbg), plain);
+    plan_launch(mp, zeroed, grid, waves_of(nbg));
     for (int j = 0; j < njobs; j++) {
         ms[j] = jobs[j].m;
         zeroed[j] = jobs[j].out_zeroed;
-        if (mp.job[j].act_out && (mp.job[j].sk != 1 || (waves_of(nbg) >> mp.job[j].log2_wpr) < 2)) return QPAL_E_SHAPE;
+        if (mp.job[j].act_out && (mp.job[j].sk != 1 || mp.plan[mp.job[j].cls].rg < 2)) return QPAL_E_SHAPE;
     }
     {
         int rc = zero_split_jobs(mp, ms, zeroed, s);
@@ -758,6 +991,63 @@ int qpal_tc_to_simt(void *dst_simt, const void *src_tc, int m, int k, int bits, 
     hipError_t e = hipMemsetAsync(dst_simt, 0, (size_t)m * k / vec * bits / 8, s);
     if (e != hipSuccess) return (int)e;
     return launch_tc_to_simt(static_cast<uint32_t *>(dst_simt), static_cast<const uint32_t *>(src_tc), m, k, bits, vec, s);
+}
+
+// Launch planner of the fused GEMV, callable without a GPU (tests/test_capi_and_host.py checks its tables: every step of every
+// row covered exactly once, at most two workgroups per row, the busiest SIMD).  See include/qpal.h.
+int qpal_plan_gemv(const int *rows, const int *steps1, const int *steps2, const int *flags, int njobs, int waves, int shared_staging,
+                   int *out, int out_len) {
+    if (!rows || !steps1 || !steps2 || !flags || !out) return QPAL_E_NULL;
+    if (njobs < 1 || njobs > kMaxJobs || (waves != 16 && waves != 8)) return QPAL_E_SHAPE;
+    TcMultiParams mp{};
+    mp.njobs = njobs;
+    int zeroed[kMaxJobs] = {0};
+    static const uint16_t dummy_x[8] = {0};
+    for (int j = 0; j < njobs; j++) {
+        TcParams &p = mp.job[j];
+        p.nrows = rows[j];
+        p.st1 = steps1[j];
+        p.st2 = steps2[j];
+        p.nsc1 = steps1[j] * 4;
+        p.nsc2 = steps2[j] * 4;
+        p.n = 1;
+        p.k = (steps1[j] + steps2[j]) * 128;
+        p.x = shared_staging ? dummy_x : dummy_x + (j % 4);  // (different x per job: groups must not span jobs)
+        zeroed[j] = flags[j] & 1;
+        p.accumulate = (flags[j] >> 1) & 1;
+        p.act_out = (flags[j] >> 2) & 1 ? reinterpret_cast<uint16_t *>(8) : nullptr;
+        if (rows[j] < 1 || steps1[j] < 1 || steps2[j] < 0) return QPAL_E_SHAPE;
+    }
+    if (!gemv_classes_ok(mp)) return QPAL_E_PARAM;
+    int grid = 0;
+    plan_launch(mp, zeroed, grid, waves);
+    const int need = 8 + 2 * (2 + 2 * kPlanMembers * kPlanWaves) + 4 * njobs;
+    if (out_len < need) return QPAL_E_SHAPE;
+    int o = 0;
+    out[o++] = grid;
+    out[o++] = mp.total_items;
+    out[o++] = mp.ncls;
+    out[o++] = mp.items0;
+    out[o++] = mp.span;
+    out[o++] = mp.cls_mask;
+    out[o++] = kPlanMembers;
+    out[o++] = kPlanWaves;
+    for (int c = 0; c < 2; c++) {
+        out[o++] = mp.plan[c].lg_g;
+        out[o++] = mp.plan[c].rg;
+        for (int m = 0; m < kPlanMembers; m++)
+            for (int w = 0; w < kPlanWaves; w++) {
+                out[o++] = (int)mp.plan[c].w[m][w].a;
+                out[o++] = (int)mp.plan[c].w[m][w].b;
+            }
+    }
+    for (int j = 0; j < njobs; j++) {
+        out[o++] = mp.job[j].cls;
+        out[o++] = mp.job[j].vrow0;
+        out[o++] = mp.row_end[j];
+        out[o++] = mp.job[j].sk;
+    }
+    return QPAL_OK;
 }
 
 int qpal_can_fuse_rotation(int n, int k) { return n >= 1 && k > 0 && rot_ok(n, k) ? 1 : 0; }

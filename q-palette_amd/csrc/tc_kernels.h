@@ -47,22 +47,14 @@ struct TcParams {
     int nsc1, nsc2;     // supertile columns of stream 1 / stream 2
     int st1, st2;       // steps (4 supertiles) per supertile row, per stream
     int col2;           // first column of stream 2 (k/2 for combt)
-    int log2_wpr;       // waves per supertile row inside a workgroup = 1 << log2_wpr (<= 16)
-    int sk;             // split-K factor across workgroups (atomics when > 1)
-    int nitems;         // work items = ceil(nrows / rows_per_wg) * sk
-    int nc1;            // of the wpr*sk chunks of a supertile row, the first nc1 belong to stream 1
+    int sk;             // GEMV: 1, or 2 = "rows are shared between workgroups: the output must start at zero" (plan_launch); lockstep GEMM
+                        // and dequant kernels: split factor across workgroups
+    int nitems;         // host only: work items of this job (lockstep GEMM / dequant)
     int x_lds;          // 1: stage x[n][k] in LDS (fits beside the codebook image)
-    int base1, rem1;    // stream 1: st1 = nc1*base1 + rem1 (first rem1 chunks get one more step)
-    int base2, rem2;    // stream 2: st2 = (nchunk-nc1)*base2 + rem2
-    // pair mode (tc_gemv_kernel, plan_launch): workgroups 2 i and 2 i + 1 own 2 R - S supertile rows (R = rows per workgroup,
-    // S = pair_shared_slots(): as many of the last row slots as it takes to put one of their waves on every SIMD — 1 at 4 or 8 waves
-    // per row, 2 at 2, 4 at 1): R - S whole rows each in their first row slots, and the last S slots of both are the same S rows,
-    // their K ranges halved between the two (atomics into a zeroed output) — every SIMD does 3.5 instead of 4 rows' worth (3 of 4
-    // at R = 2): a layer of 896 rows (gate | up of Llama-8B, R = 4; of Llama-70B, R = 8) runs on 256 instead of 224 CUs.
-    // Encoded as sk == -1, with NO fields of its own: the kernel is at its SGPR limit (6 more dwords of job made the compiler spill
-    // the preloaded arguments and wait for the kernel-argument block three times: -5 % tokens/s with pair mode off).  The planner
-    // uses it only where the chunk partition halves exactly: rem1 == rem2 == 0, base1 and base2 even — the shared slot then has
-    // 2 nc1 stream-1 chunks of base1 / 2 steps (and base2 / 2 on stream 2).
+    // GEMV launch geometry (round 5): the launch's jobs of one geometry class form ONE row space — job j's rows are the virtual rows
+    // [vrow0, vrow0 + nrows) of its class — and the kernel finds a wave's (row, stream, steps) in the launch's table (LaunchPlan)
+    int cls;            // geometry class (index into TcMultiParams::plan)
+    int vrow0;          // first virtual row
     int kv;                  // TcqAny kernels only: this job's KV (trellis dwords per lane)
     int kv2;                 // TcqAny kernels only: KV of stream 2 of a column-split (combt) job, 0: single stream
     const uint16_t *x_su;    // gemv prologue rotation (x_rot != 0): fp16 [k] sign vector or null
@@ -84,8 +76,22 @@ struct TcParams {
                              // writes fp16 silu(gate) * up [m / 2] here instead of `out` (rows per workgroup >= 2, no split-K)
 };
 
-// pair mode: row slots of a workgroup that it shares with its partner (host and device)
-__host__ __device__ inline int pair_shared_slots(int log2_wpr) { return log2_wpr >= 2 ? 1 : 4 >> log2_wpr; }
+// One launch's geometry, planned on the host (qpal_capi.hip plan_launch: "tape cut") and read by every wave from the kernel-argument
+// block: a GROUP of (1 << lg_g) workgroups owns rg consecutive virtual rows; w[member][wave] says what that wave does.
+//   a: [7:0] row inside the group, [8] stream 2, [9] lead = first wave of its row's run of waves in this workgroup (it sums the run's
+//      partials and writes the row), [10] the row is shared with another workgroup (atomic add into a zeroed / accumulated output),
+//      [15:11] waves in the run (lead only), [16] the wave has steps, [17] lead of an `up` row that also finishes the `gate` row
+//      behind it with its upper 32 lanes (SwiGLU epilogue)
+//   b: [15:0] first step inside the stream, [31:16] number of steps
+constexpr int kPlanMembers = 4;
+constexpr int kPlanWaves = 16;
+struct WaveEnt {
+    uint32_t a, b;
+};
+struct LaunchPlan {
+    int lg_g, rg;
+    WaveEnt w[kPlanMembers][kPlanWaves];
+};
 
 constexpr int kMaxJobs = 8;
 
@@ -98,7 +104,14 @@ struct TcMultiParams {
     int total_items;
     int zero_chunks;   // 16-byte chunks of `zero` this launch fills with zeros (0: none)
     u32x4 *zero;       // buffer pre-zeroed for a later split-K launch on the same stream
-    int item_end[kMaxJobs];
+    int item_end[kMaxJobs];   // lockstep GEMM kernel (tc_gemm.h): items of jobs 0..j
+    // fused GEMV kernel (round 5): table-driven geometry
+    int ncls;                 // geometry classes in this launch (1 or 2)
+    int span;                 // 1: groups may reach into the next job (the jobs agree on what a workgroup stages; every job holds a group's rows)
+    int items0;               // items (workgroup-sized pieces of work) of class 0; class 1 follows
+    int cls_mask;             // bit j: job j belongs to class 1
+    int row_end[kMaxJobs];    // end of job j's virtual rows inside its class's row space (padded to whole groups unless groups may span jobs)
+    LaunchPlan plan[2];
     TcParams job[kMaxJobs];
 };
 
@@ -645,9 +658,10 @@ struct TcEarly {
     const uint16_t *su;  // rotating launches: sign vector (or null), RMSNorm weight (or null; the 14336-wide rotation: its hadK factor)
     const uint16_t *rw;
     float pre, post;     // the 14336-wide rotation: x_pre, x_post
-    int ie;              // != 0: item_end[0..2] of the launch's job table, 10 bits each (0x3ff: no such boundary), bit 30 set — a workgroup
-                         // knows the job of its FIRST item before the kernel-argument block has arrived, and requests THAT job's
-                         // parameters in the first scalar-load round trip (launches of <= 4 jobs; 0: it scans the table as before)
+    int ie;              // != 0 (bit 30): row_end[0..2] of the launch's jobs, 10 bits each (0x3ff: no such boundary), and `on` carries the
+                         // plan's header (bits 16..17 lg_g, 18..24 rg) — a wave knows its table entry's address and its group's job before
+                         // the kernel-argument block has arrived, and requests both in the first scalar-load round trip (one geometry
+                         // class, <= 4 jobs; 0: it reads the plan header and scans the row table first)
 };
 
 // host: the launch qualifies when x is staged in LDS and every job has the same x, codebook and batch
@@ -668,14 +682,15 @@ inline TcEarly early_args(const TcMultiParams &mp) {
             b.x_pre != a.x_pre || b.x_post != a.x_post)
             e.on = 0;
     }
+    // Fast path of the kernel's row lookup: one geometry class, <= 4 jobs, row ends below 1023 — the plan's header and the jobs' row
+    // ends travel as preloaded arguments, so the first kernel-argument round trip can fetch the wave's table entry AND its job.
     e.ie = 0;
-    if (mp.njobs >= 2 && mp.njobs <= 4) {  // (one job: nothing to find out)
+    if (mp.ncls == 1 && mp.njobs <= 4 && mp.row_end[mp.njobs - 1] < 0x3ff && mp.plan[0].rg < 128) {
         e.ie = 1 << 30;
-        for (int j = 0; j < 3; j++) {
-            const int end = j < mp.njobs - 1 ? mp.item_end[j] : 0x3ff;
-            e.ie |= (end < 0x3ff ? end : 0x3ff) << (10 * j);
-        }
+        for (int j = 0; j < 3; j++) e.ie |= (j < mp.njobs - 1 ? mp.row_end[j] : 0x3ff) << (10 * j);
+        e.on |= (mp.plan[0].lg_g << 16) | (mp.plan[0].rg << 18);
     }
+    if (mp.span) e.on |= 1 << 25;
     return e;
 }
 
@@ -730,7 +745,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                                                        const uint16_t *esu, const uint16_t *erw, const TcMultiParams mp) {
     constexpr bool TWO = !std::is_void_v<C2>;
     using CB = std::conditional_t<TWO, C2, C1>;
-    constexpr int W = gemv_waves<NBG>(), LOG2W = W == 16 ? 4 : 3, NT = 64 * W;
+    constexpr int W = gemv_waves<NBG>(), NT = 64 * W;
     static_assert(!ROT || NBG == 1, "fused rotation: batch 1 kernels");
     __shared__ __attribute__((aligned(16))) uint32_t lut[C1::LDS_DWORDS];
     __shared__ __attribute__((aligned(16))) unsigned char scratch[scratch_bytes<NBG>()];
@@ -758,7 +773,6 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     // 8.3 us (llama3.1-8b_figure1c 651 -> 707 tok/s, mem3p25 678 -> 722, one box: profiles/r03_ab_any_spills.txt).
     constexpr bool kXPerm = QPAL_XPERM_PLAIN != 0 && (ROT == 0 || ROT == 3);  // staged x in the permuted layout (xs_put)
     constexpr int kXL = kXPerm ? 2 : 1;
-    constexpr bool PAIRK = ROT == 3;  // plain kernel that also understands pair-mode jobs (sk == -1, TcParams)
 #ifndef QPAL_ANY_EARLY
 #define QPAL_ANY_EARLY 1  // round 4: with the early loads outside the compiler's bookkeeping (inline asm) and the first item as its own
 #endif                    // body, the any-KV kernels hold them without spilling (round 3: 16-28 spilled VGPRs, early staging off)
@@ -863,37 +877,80 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
             for (int r = 0; r < C1::CHUNKS / 1024; r++) C1::raw_issue(etab, ((tid + r * 1024) * 4) >> C1::LOG2C, ev28[r]);
         }
     }
-    // one scalar-load round trip for everything the first item needs: the item table and job 0
-    int ie[kMaxJobs];
-#pragma unroll
-    for (int i = 0; i < kMaxJobs; i++) ie[i] = mp.item_end[i];
-    // Which job does this workgroup's FIRST item belong to?  From the preloaded `eie` (early_args), i.e. before any kernel argument
-    // has arrived: the first round trip then fetches THAT job.  (Round 4: workgroups of jobs 1.. — a third of a q | k | v launch,
-    // half of a gate | up launch, and the launch ends with its slowest workgroup — scanned the item table after the first round
-    // trip and fetched their job in a second, dependent one: ~40 more scalar instructions and a memory round trip in front of their
-    // first weight loads.)
-    int jf = 0, ibf = 0;
-    if (eie != 0) {
-        const int b = (int)blockIdx.x, e0 = eie & 0x3ff, e1 = (eie >> 10) & 0x3ff, e2 = (eie >> 20) & 0x3ff;
-        if (b >= e0) {  // (nested: a workgroup of job 0 — most of them — leaves after one comparison)
-            jf = 1, ibf = e0;
-            if (b >= e1) {
-                jf = 2, ibf = e1;
-                if (b >= e2) jf = 3, ibf = e2;
+    // ---- Which rows?  (Round 5: the launch's geometry is a host-planned table, TcMultiParams::plan — see LaunchPlan.)
+    // Workgroup `item` of geometry class c is member (item mod G) of group (item / G); the group owns rg consecutive virtual rows of
+    // the class's row space, and w[member][wave] names this wave's row inside the group, its stream and its steps.  The row's JOB
+    // follows from the jobs' row ends.  FAST PATH (eie != 0: one class, <= 4 jobs): lg_g, rg and the row ends are preloaded, so the
+    // addresses of the table entry and of the job of the group's FIRST row are known before any kernel argument has arrived — one
+    // scalar-load round trip fetches both, plus the stream pointers of the job BEHIND it (a group may reach into the next job: its
+    // waves there pick those, and re-fetch the rest of that job behind the staging barrier, off the path to the first weights).
+    // Everything on the way to the first weight loads is in this one batch (round 4: a second, dependent round trip there cost
+    // 0.3-0.4 us per launch).
+    const bool fast = eie != 0;
+    struct JobB {  // the job behind a group's first job: what a wave needs of it BEFORE its first weight loads (its first virtual row
+        const uint32_t *c1, *c2;  // is the end of the job in front of it: spanning groups pack the jobs back to back)
+        int nrows, kv, kv2;
+    };
+    auto job_b = [&](int j) {
+        if constexpr (is_any_v<C1>) return JobB{mp.job[j].c1, mp.job[j].c2, mp.job[j].nrows, mp.job[j].kv, mp.job[j].kv2};
+        else return JobB{mp.job[j].c1, mp.job[j].c2, mp.job[j].nrows, 0, 0};
+    };
+    struct Where {  // a wave's place in the launch
+        WaveEnt ent;
+        int row0;   // first virtual row of its group
+        int jA;     // job of that row
+        int endA;   // end of jA's virtual rows
+        int jB;     // the job behind jA (jA itself when there is none)
+    };
+    // generic lookup (launches the fast path does not cover, and the later items of a workgroup in launches of more than one round):
+    // plan header, table entry and the row table come from the kernel-argument block, the job in a second, dependent round trip
+    auto lookup = [&](int gitem) {
+        int c = 0, item = gitem;
+        if (mp.ncls > 1 && item >= mp.items0) {
+            c = 1;
+            item -= mp.items0;
+        }
+        const int lgg = mp.plan[c].lg_g;
+        Where wh;
+        wh.row0 = (item >> lgg) * mp.plan[c].rg;
+        wh.ent = mp.plan[c].w[item & ((1 << lgg) - 1)][wave];
+        int jA = -1, jB = -1, endA = 0x7fffffff, last = 0;
+#pragma unroll 1  // (a scalar loop: unrolled, its eight row ends and masks cost the kernel's other paths their scalar registers)
+        for (int i = 0; i < mp.njobs; i++) {
+            const bool mine = ((mp.cls_mask >> i) & 1) == c;
+            if (mine) last = i;
+            if (mine && jA >= 0 && jB < 0) jB = i;
+            if (mine && jA < 0 && wh.row0 < mp.row_end[i]) {
+                jA = i;
+                endA = mp.row_end[i];
             }
         }
+        wh.jA = jA < 0 ? last : jA;  // (rows behind the class's last job: dead rows of the last group)
+        wh.jB = jB < 0 ? wh.jA : jB;
+        wh.endA = endA;
+        return wh;
+    };
+    // the first item on the fast path: everything from preloaded arguments, its loads form the first batch
+    Where f_wh{};
+    {
+        const int lgg = (eon >> 16) & 3, item = blockIdx.x;
+        f_wh.row0 = (item >> lgg) * ((eon >> 18) & 127);
+        f_wh.ent = mp.plan[0].w[item & ((1 << lgg) - 1)][wave];
+        const int e0 = eie & 0x3ff, e1 = (eie >> 10) & 0x3ff, e2 = (eie >> 20) & 0x3ff;
+        f_wh.jA = (f_wh.row0 >= e0 ? 1 : 0) + (f_wh.row0 >= e1 ? 1 : 0) + (f_wh.row0 >= e2 ? 1 : 0);
+        f_wh.endA = f_wh.jA == 0 ? e0 : f_wh.jA == 1 ? e1 : f_wh.jA == 2 ? e2 : 0x3ff;
+        f_wh.jB = f_wh.endA < 0x3ff ? f_wh.jA + 1 : f_wh.jA;  // (0x3ff: no job behind it)
     }
-    TcParams p = mp.job[jf];
-    cur_j = jf;
-    const int total_items = ie[kMaxJobs - 1];
-    // Pin job 0's loads next to the item table's: left alone, the compiler requests job 0 only inside the loop, after
-    // it has waited for the item table — two kernel-argument round trips on the critical path instead of one.
-    // (round 4: EVERYTHING the path to the first weight loads reads — the chunk partition, nsc2, x_lds, the prezero count — or it is
-    // a second, dependent round trip: the stamps had the arguments "in hand" 0.76 us after the wave's entry with two batches)
-    asm volatile("" ::"s"(p.c1), "s"(p.c2), "s"(p.x), "s"(p.tab), "s"(p.nrows), "s"(p.nsc1), "s"(p.log2_wpr), "s"(p.sk),
-                 "s"(p.out), "s"(ie[0]), "s"(p.wscale), "s"(p.base2), "s"(p.nsc2), "s"(p.nc1), "s"(p.base1), "s"(p.rem1), "s"(p.rem2),
-                 "s"(p.x_lds), "s"(p.n), "s"(p.k), "s"(mp.zero_chunks), "s"(p.ldo), "s"(p.accumulate),
-                 "s"(__builtin_bit_cast(uint32_t, p.oscale)));
+    if (!fast) f_wh = lookup(blockIdx.x);
+    TcParams p = mp.job[f_wh.jA];
+    cur_j = f_wh.jA;
+    const bool span = (eon & (1 << 25)) != 0;  // groups may reach into the next job (host: plan_launch)
+    const JobB f_B = job_b(span ? f_wh.jB : f_wh.jA);  // (no branch here: a branch puts a wait for job A between the two batches)
+    // Pin the batch: left alone, the compiler requests the job only inside the item, after it has waited for the table entry.
+    // (round 5: what only the epilogue reads — out, ldo, wscale, oscale, accumulate — is requested behind the first weight loads
+    // instead, see there: held from here it pushed the kernel over its scalar-register budget, and every spill is a wait)
+    asm volatile("" ::"s"(p.c1), "s"(p.c2), "s"(p.x), "s"(p.tab), "s"(p.nrows), "s"(p.nsc1), "s"(p.vrow0), "s"(f_wh.ent.a), "s"(f_wh.ent.b),
+                 "s"(p.nsc2), "s"(f_B.c1), "s"(f_B.c2), "s"(f_B.nrows), "s"(p.x_lds), "s"(p.n), "s"(p.k), "s"(mp.zero_chunks));
     // One work item.  FIRST (this workgroup's first item, compile-time): the only one that consumes the early-staged registers —
     // a body of its own, so that those registers are plain straight-line values.  (Measured against ONE body with the early wait
     // in front of the item loop, profiles/r04_ab_prologue.txt: the single body is 0.3-0.4 us slower on every short launch —
@@ -908,34 +965,21 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
             uint32_t a[C1::NW];
             uint32_t b[TWO ? CB::NW : 1];
         } w;
-        // Which job?  Most workgroups work on job 0: two scalar instructions for them instead of the branch-free scan of the whole
-        // table (~60 scalar instructions; round 4: the prologue is bound by instruction ISSUE — four waves per SIMD executing the
-        // same scalar code get an issue slot every ~16 cycles each, and ~200 instructions stood between a wave's entry and its
-        // first weight load: ~1 us of a 5-6 us launch)
-        int j = 0, item_begin = 0;
-        if (FIRST && eie != 0) {
-            j = jf;
-            item_begin = ibf;
-        } else if (gitem >= ie[0]) {
-#pragma unroll
-            for (int i = 0; i < kMaxJobs - 1; i++) {
-                if (gitem >= ie[i]) {
-                    j = i + 1;
-                    item_begin = ie[i];
-                }
+        // this wave's table entry, its group's first job (A) and the stream pointers of the job behind it (B)
+        Where wh = f_wh;
+        JobB B = f_B;
+        if constexpr (!FIRST) {
+            wh = lookup(gitem);
+            if (wh.jA != cur_j) {
+                p = mp.job[wh.jA];
+                cur_j = wh.jA;
             }
+            B = job_b(span ? wh.jB : wh.jA);
         }
-        if (j != cur_j) {
-            p = mp.job[j];
-            cur_j = j;
-        }
-        const int item = gitem - item_begin;
+        const WaveEnt ent = wh.ent;
+        const int row0 = wh.row0, endA = wh.endA, jB = wh.jB;
         float *red = reinterpret_cast<float *>(scratch);                           // [W][n][32]
         uint16_t *xs = reinterpret_cast<uint16_t *>(scratch + W * 32 * 4 * p.n);   // [n][k] + 32 zero halves
-        const int wpr = 1 << p.log2_wpr;
-        const int rloc = wave >> p.log2_wpr;  // supertile row inside the workgroup's row group
-        const int wr = wave & (wpr - 1);      // this wave's K-chunk inside the row
-        const int log2_rpw = LOG2W - p.log2_wpr;  // log2(rows per workgroup)
         const int zero_off = p.n * p.k;
         const bool x_lds = NBG == 1 && p.x_lds;
 #ifdef QPAL_STAMPS  // stamp 0 (kernel arguments in hand) carries the time since the wave's first instruction in its bits 52..63
@@ -944,57 +988,32 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
             p.dbg[((long)blockIdx.x * 16 + wave) * 8] = (t_now & ((1ull << 52) - 1)) | ((t_now - t_entry) << 52);
         }
 #endif
-
-        int rg = item, ks = 0;
-        if (p.sk > 1) {  // (a power of two: plan_launch; a division is ~35 instructions here)
-            const int lsk = 31 - __builtin_clz((unsigned)p.sk);
-            rg = item >> lsk;
-            ks = item & (p.sk - 1);
-        }
-        // row slot rl of this workgroup -> supertile row (pair mode: sk == -1, see TcParams); everything recomputed where it is
-        // used rather than kept in SGPRs across the steps
-        // (ROT == 3 kernels only — the same code in every plain kernel cost them 2.4 % with pair mode off: SGPRs.  Branch-free:
-        // slot rl < last -> row_base + rl, the last slot -> row_last; sk == -1: rg is the item)
-        // whole slots rl < wholes -> row_base + rl; shared slots -> row_shared + rl (one form for both modes: wholes = R, no pair)
-        int row_base = rg << log2_rpw;
-        [[maybe_unused]] int wholes = 1 << log2_rpw, row_shared = 0;
-        bool shared = false;  // wave-uniform
-        if constexpr (PAIRK) {
-            if (p.sk < 0) {
-                wholes = (1 << log2_rpw) - pair_shared_slots(p.log2_wpr);
-                const int pair_rows = (1 << log2_rpw) + wholes;
-                row_base = (rg >> 1) * pair_rows + (rg & 1) * wholes;
-                row_shared = (rg >> 1) * pair_rows + wholes;  // + rl: rows 2 wholes ... of the pair
-                shared = rloc >= wholes;
-            }
-        }
-        auto row_of = [&](int rl) {
-            if constexpr (PAIRK) return rl >= wholes ? row_shared + rl : row_base + rl;
-            else return row_base + rl;
-        };
-        const int sr = row_of(rloc);
-        const bool live = sr < p.nrows;
-        // (measured and not kept: chunk wr * sk + ks for single-stream split-K rows, so that the `rem` longer chunks alternate
-        // between the workgroups of a row — Llama-8B down_proj in tcq_6: 14 / 14 instead of 16 / 12 steps per SIMD — moved
-        // nothing: tcq_6 +0.6 %, ldlq_1_4 -0.7 %, 70B +-0 (profiles/r03_ab_interleave_rem.txt).  That launch streams 23.9 MB in a
-        // ~5 us steps phase = 4.8 TB/s: its steps phase is HBM-bound as much as decode-bound)
-        const int c = (shared ? (rg & 1) : ks) * wpr + wr;
-        // chunk c -> (stream, [s0, s1)): chunk j of a stream covers base steps, the first rem chunks one more
-        // (any-KV kernels take column-split jobs too: the two streams are two KV of the same codebook size, and the waves of a
-        // row pick their decode loop by the stream their chunk lies in — a wave-uniform choice)
+        // the wave's row: virtual row -> (job, row inside the job).  in_b: the row lies behind job A's rows, i.e. in job B (the
+        // planner lets a group reach into the next job only where every job has at least a group's rows and the jobs agree on
+        // everything a workgroup shares: x, codebook, batch, rotation — so one boundary per group at most, and the staging below
+        // may read those from either job)
+        const int vrow = row0 + (int)(ent.a & 255u);
+        const bool in_b = span && vrow >= endA;
+        const int sr = vrow - (in_b ? endA : p.vrow0);              // supertile row inside its job
+        const int nrows_j = in_b ? B.nrows : p.nrows;
+        const bool live = sr < nrows_j && ((ent.a >> 16) & 1u) != 0;
+        // (the entry's epilogue bits — lead, shared row, run length — are cut out of `ea` again BEHIND the steps: one scalar register
+        // held across them instead of four)
+        uint32_t ea = ent.a;
+        // (stream, [s0, s1)) of the wave's piece (any-KV kernels take column-split jobs too: the two streams are two KV of the same
+        // codebook size, and a wave picks its decode loop by the stream its piece lies in — a wave-uniform choice)
         constexpr bool ANY = is_any_v<C1>;
-        const int nc1 = shared ? 2 * p.nc1 : p.nc1;
-        const bool on2 = (TWO || (ANY && p.kv2 != 0)) && c >= nc1;
-        const int cc = on2 ? c - nc1 : c;
-        const int base = (on2 ? p.base2 : p.base1) >> (shared ? 1 : 0), rem = on2 ? p.rem2 : p.rem1;  // (pair mode: rem == 0)
-        int s0 = cc * base + (cc < rem ? cc : rem);
-        int s1 = s0 + base + (cc < rem ? 1 : 0);
+        const int kv1_j = in_b ? B.kv : p.kv, kv2_j = in_b ? B.kv2 : p.kv2;
+        const bool two_rt = TWO || (ANY && kv2_j != 0);
+        const bool on2 = two_rt && ((ent.a >> 8) & 1u) != 0;
+        int s0 = (int)(ent.b & 0xffffu);
+        int s1 = s0 + (int)(ent.b >> 16);
         if (!live) s0 = s1 = 0;
-        const int nw1 = ANY ? p.kv : C1::NW;  // dwords per lane per supertile of stream 1
-        const int nw2 = ANY ? p.kv2 : CB::NW;
-        const bool two_rt = TWO || (ANY && p.kv2 != 0);
-        const StreamView sv1{p.c1 + (long)(live ? sr : 0) * p.nsc1 * 16 * nw1, p.nsc1, 0};
-        const StreamView sv2{two_rt ? p.c2 + (long)(live ? sr : 0) * p.nsc2 * 16 * nw2 : p.c1, two_rt ? p.nsc2 : p.nsc1,
+        const int nw1 = ANY ? kv1_j : C1::NW;  // dwords per lane per supertile of stream 1
+        const int nw2 = ANY ? kv2_j : CB::NW;
+        const uint32_t *c1_j = in_b ? B.c1 : p.c1, *c2_j = in_b ? B.c2 : p.c2;
+        const StreamView sv1{c1_j + (long)(live ? sr : 0) * p.nsc1 * 16 * nw1, p.nsc1, 0};
+        const StreamView sv2{two_rt ? c2_j + (long)(live ? sr : 0) * p.nsc2 * 16 * nw2 : c1_j, two_rt ? p.nsc2 : p.nsc1,
                              p.col2};
         // Early staging, part 2a: the early loads were issued from inline asm, i.e. outside the compiler's wait-count bookkeeping —
         // wait for them by hand, HERE: ~0.2-0.3 us after the wave's entry they and the kernel arguments have arrived together
@@ -1061,7 +1080,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         }
         // first step's weights are in flight while x and the codebook image are (re)staged
         if constexpr (ANY) {
-            dispatch_kv<C1::S_>(on2 ? p.kv2 : p.kv, [&](auto kc) {
+            dispatch_kv<C1::S_>(on2 ? kv2_j : kv1_j, [&](auto kc) {
                 constexpr int KVr = decltype(kc)::value;
                 load_step_w<KVr>(on2 ? sv2 : sv1, s0, lane, reinterpret_cast<uint32_t(&)[KVr]>(w.a));
             });
@@ -1074,6 +1093,8 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
             }
         }
         QPAL_STAMP(1);  // (the first weights are requested)
+        if constexpr (FIRST)  // the epilogue's job fields: one more scalar-load batch, in the shadow of the weight loads
+            asm volatile("" ::"s"(p.out), "s"(p.wscale), "s"(p.ldo), "s"(p.accumulate), "s"(__builtin_bit_cast(uint32_t, p.oscale)));
         if constexpr (kEarly) {
             if (FIRST && early) {  // early staging, part 2b: registers -> LDS
                 const int total = en * ek;
@@ -1257,10 +1278,20 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         uint32_t wraw;
         asm volatile("" : "=v"(wraw));  // "no value yet": a constant here would be merged with the load at the join
                                         // below, and the merge waits for the load on the spot
-        if (p.wscale && tid < (32 << log2_rpw) && row_of(tid >> 5) < p.nrows)
-            wraw = p.wscale[row_of(tid >> 5) * 32 + (tid & 31)];
+        // A wave whose row lies in the job BEHIND its group's first job: the rest of that job (output, scales, flags) — fetched here,
+        // behind the first weight loads and the staging barrier (everything the staging read is the same in both jobs).
+        if (in_b && jB != cur_j) {
+            p = mp.job[jB];
+            cur_j = jB;
+        }
+        // The lead wave of a run finishes its row with lanes 0..31 (lanes 32..63: the gate row behind an up row, SwiGLU epilogue only)
+        const int fr = lane & 31, fhi = lane >> 5;
+        bool fin = ((ea >> 9) & 1u) != 0 && live && fhi == 0;   // lead: first wave of its row's run — it sums the run and writes the row
+        if constexpr (ROT == 1) fin = ((ea >> 9) & 1u) != 0 && live && (fhi == 0 || (((ea >> 17) & 1u) != 0 && sr + 1 < nrows_j));
+        const int fsrow = sr + fhi;
+        if (p.wscale && fin) wraw = p.wscale[fsrow * 32 + fr];
         if constexpr (ANY) {
-            dispatch_kv<C1::S_>(on2 ? p.kv2 : p.kv, [&](auto kc) {
+            dispatch_kv<C1::S_>(on2 ? kv2_j : kv1_j, [&](auto kc) {
                 constexpr int KVr = decltype(kc)::value;
                 using CK = TcqCodec<C1::S_, KVr>;
                 auto &wk = reinterpret_cast<uint32_t(&)[KVr]>(w.a);
@@ -1309,61 +1340,58 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
             });
         }
         // (what the final sum needs besides the partials — row, scale, destination — is worked out in FRONT of the barrier: behind it
-        // only the reducing wave runs, and everything there is the launch's tail)
-        const int fr = tid & 31, frl = tid >> 5;
-        const bool fin = tid < (32 << log2_rpw);
-        const int fsrow = fin ? row_of(frl) : 0;
+        // only the lead waves run, and everything there is the launch's tail)
+        asm volatile("" : "+s"(ea));
+        const bool lead = ((ea >> 9) & 1u) != 0;                       // (wave-uniform)
+        const bool row_shared = ((ea >> 10) & 1u) != 0;                 // another workgroup adds to the same row: atomics
+        const int run_waves = (int)((ea >> 11) & 31u);
+        [[maybe_unused]] const bool lead2 = ((ea >> 17) & 1u) != 0;     // (SwiGLU) the lead of an up row also finishes the gate row behind it
         float fosc = (fin && p.wscale) ? p.oscale * (float)__builtin_bit_cast(_Float16, (uint16_t)wraw) : p.oscale;
         int fdoff = fsrow * 32 + fr;                          // (offsets, not pointers: a pointer through an asm loses its address space)
-        int froff = (frl << p.log2_wpr) * p.n * 32 + fr;
+        int froff = (wave + fhi * run_waves) * p.n * 32 + fr;  // the run's first partial (lanes 32..63: the next run's)
         asm volatile("" : "+v"(fosc), "+v"(fdoff), "+v"(froff));
         float *fdst = p.out + fdoff;
         const float *fred = red + froff;
         QPAL_STAMP(5);
         __syncthreads();
         QPAL_STAMP(6);
-        if (fin) {
-            const int r = fr, rl = frl;
-            const int srow = fsrow;
+        if (lead) {  // (wave-uniform)
             [[maybe_unused]] bool continue_item = false;
-            if (srow < p.nrows) {
-                // the incoherent wrappers' `* Wscale * scale`, fused
-                const float osc = fosc;
-                if constexpr (ROT == 1) {
-                    if (p.act_out) {  // SwiGLU of an interleaved up | gate layer: threads (rl, r) and (rl + 1, r) are lanes r, r + 32
-                        float v = 0.f;
-                        for (int qq = 0; qq < wpr; qq++) v += red[((rl << p.log2_wpr) + qq) * 32 + r];
-                        const float mine = (float)(_Float16)(v * osc);           // the reference's fp16 up / gate
-                        const float gate = lane_xor<32>(mine);  // (lanes r < 32 read lane r + 32: a permlane swap, not an LDS permute)
-                        if ((rl & 1) == 0) {
-                            const float sg = (float)(_Float16)(gate * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gate * -1.44269504f)));
-                            uint16_t av = __builtin_bit_cast(uint16_t, (_Float16)(sg * mine));
-                            if (p.act_su) av ^= p.act_su[(long)(srow >> 1) * 32 + r] & 0x8000u;  // * (+-1): flip the sign bit
-                            p.act_out[(long)(srow >> 1) * 32 + r] = av;
-                        }
-                        continue_item = true;
-                    }
-                }
-                if (!continue_item)
-                for (int b = 0; b < p.n; b++) {
+            // the incoherent wrappers' `* Wscale * scale`, fused
+            const float osc = fosc;
+            if constexpr (ROT == 1) {
+                if (p.act_out) {  // SwiGLU of an interleaved up | gate layer: up row in lanes r, the gate row behind it in lanes r + 32
                     float v = 0.f;
-                    for (int qq = 0; qq < wpr; qq++) v += fred[(qq * p.n + b) * 32];
-                    float *dst = fdst + (long)b * p.ldo;
-                    v *= osc;
-                    if (p.sk > 1 || (PAIRK && p.sk < 0 && rl >= wholes)) atomicAdd(dst, v);
-                    else if (p.accumulate) *dst += v;  // the residual add of a decoder block: out is the fp32 residual stream
-                    else *dst = v;
+                    for (int qq = 0; qq < run_waves; qq++) v += fred[qq * 32];
+                    const float mine = (float)(_Float16)(v * osc);           // the reference's fp16 up / gate
+                    const float gate = lane_xor<32>(mine);  // (lanes r < 32 read lane r + 32: a permlane swap, not an LDS permute)
+                    if (fin && fhi == 0 && lead2) {  // (the gate row's own lead wave has nothing to do here)
+                        const float sg = (float)(_Float16)(gate * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gate * -1.44269504f)));
+                        uint16_t av = __builtin_bit_cast(uint16_t, (_Float16)(sg * mine));
+                        if (p.act_su) av ^= p.act_su[(long)(fsrow >> 1) * 32 + fr] & 0x8000u;  // * (+-1): flip the sign bit
+                        p.act_out[(long)(fsrow >> 1) * 32 + fr] = av;
+                    }
+                    continue_item = true;
                 }
+            }
+            if (!continue_item && fin)
+            for (int b = 0; b < p.n; b++) {
+                float v = 0.f;
+                for (int qq = 0; qq < run_waves; qq++) v += fred[(qq * p.n + b) * 32];
+                float *dst = fdst + (long)b * p.ldo;
+                v *= osc;
+                if (row_shared) atomicAdd(dst, v);
+                else if (p.accumulate) *dst += v;  // the residual add of a decoder block: out is the fp32 residual stream
+                else *dst = v;
             }
         }
         QPAL_STAMP(7);
         __syncthreads();
     };
+    // (the grid never exceeds the item count: host, plan_launch; the count is read only once the first item is done)
     int gitem = blockIdx.x;
-    if (gitem < total_items) {
-        run_item(gitem, std::true_type{});
-        for (gitem += gridDim.x; gitem < total_items; gitem += gridDim.x) run_item(gitem, std::false_type{});
-    }
+    run_item(gitem, std::true_type{});
+    for (gitem += gridDim.x; gitem < mp.total_items; gitem += gridDim.x) run_item(gitem, std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------------

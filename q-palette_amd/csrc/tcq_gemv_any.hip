@@ -6,15 +6,6 @@ namespace qpal {
 
 int launch_tcq_gemv_any(const TcMultiParams &p, int S, int grid, hipStream_t stream) {
     const TcEarly e = early_args(p);
-    bool pair = false;  // pair mode (TcParams: sk == -1): the pair-aware instantiation (round 4: mixed-scheme gate | up launches)
-    for (int j = 0; j < p.njobs; j++) pair = pair || p.job[j].sk < 0;
-    if (pair) {
-        if (S == 9) hipLaunchKernelGGL((tc_gemv_kernel<TcqAny<9>, void, 1, 3>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, p);
-        else if (S == 10) hipLaunchKernelGGL((tc_gemv_kernel<TcqAny<10>, void, 1, 3>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, p);
-        else if (S == 11) hipLaunchKernelGGL((tc_gemv_kernel<TcqAny<11>, void, 1, 3>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, p);
-        else return QPAL_E_PARAM;
-        return (int)hipGetLastError();
-    }
     if (S == 9) hipLaunchKernelGGL((tc_gemv_kernel<TcqAny<9>, void, 1, false>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, p);
     else if (S == 10) hipLaunchKernelGGL((tc_gemv_kernel<TcqAny<10>, void, 1, false>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, p);
     else if (S == 11) hipLaunchKernelGGL((tc_gemv_kernel<TcqAny<11>, void, 1, false>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, p);

@@ -26,8 +26,8 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
         if (slot < 0 && nkeys < 8) {
             slot = nkeys;
             keys[nkeys++] = key;
-            fprintf(stderr, "[stamps-slot] %d %s grid %d m %d k %d wpr %d sk %d\n", slot, ROT == 3 ? "pair" : ROT ? "rot" : "plain", grid, p.nrows * 32, p.k,
-                    1 << p.log2_wpr, p.sk);
+            fprintf(stderr, "[stamps-slot] %d %s grid %d m %d k %d groups of %d x %d rows\n", slot, ROT ? "rot" : "plain", grid, p.nrows * 32, p.k,
+                    1 << mp.plan[0].lg_g, mp.plan[0].rg);
         }
         if (slot >= 0 && grid <= 256) {
             TcMultiParams mq = mp;
@@ -74,14 +74,14 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
                 prev = cur;
             }
         }
-        printf("[stamps] %s grid %d m %d k %d wpr %d sk %d: first stamp -> last stamp %.2f us (wave starts spread over %.2f us, wave ends over %.2f us); mean / max per-wave phase (us):", ROT == 3 ? "pair" : ROT ? "ROT" : "plain", grid,
-               p.nrows * 32, p.k, 1 << p.log2_wpr, p.sk, (t7 - t0) / 100.0, (t0max - t0) / 100.0, (t7 - t7min) / 100.0);
+        printf("[stamps] %s grid %d m %d k %d groups of %d x %d rows: first stamp -> last stamp %.2f us (wave starts spread over %.2f us, wave ends over %.2f us); mean / max per-wave phase (us):", ROT ? "ROT" : "plain", grid,
+               p.nrows * 32, p.k, 1 << mp.plan[0].lg_g, mp.plan[0].rg, (t7 - t0) / 100.0, (t0max - t0) / 100.0, (t7 - t7min) / 100.0);
         const char *nm[8] = {"", "issue-w", "x+lut", "barrier", "steps", "xor-red", "barrier2", "final"};
         for (int i = 1; i < 8; i++) printf(" %s %.2f/%.2f", nm[i], ph[i] / (nw ? nw : 1) / 100.0, phmax[i] / 100.0);
         printf("\n");
         if (const char *dump = getenv("QPAL_STAMPS_DUMP")) {  // raw stamps for offline analysis: one binary file per stamped launch
             char path[512];
-            snprintf(path, sizeof path, "%s_%s_grid%d_m%d_k%d.bin", dump, ROT == 3 ? "pair" : ROT ? "rot" : "plain", grid, p.nrows * 32, p.k);
+            snprintf(path, sizeof path, "%s_%s_grid%d_m%d_k%d.bin", dump, ROT ? "rot" : "plain", grid, p.nrows * 32, p.k);
             if (FILE *f = fopen(path, "wb")) {
                 fwrite(h, 1, nb, f);
                 fclose(f);

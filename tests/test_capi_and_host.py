@@ -313,3 +313,126 @@ def test_early_load_registers_are_untouched_until_their_wait():
     br = ("s_cbranch_scc1", "3", 10, 16)
     n, bad = chk.check_kernel("k", [ld, fetch, br, wait0, use, end])
     assert n == 1 and len(bad) == 1
+
+
+def _plan(rows, st1, st2, flags, waves=16, shared=1):
+    import ctypes
+    n = len(rows)
+    arr = lambda v: (ctypes.c_int * n)(*v)
+    out = (ctypes.c_int * 1024)()
+    rc = qp._native.lib().qpal_plan_gemv(arr(rows), arr(st1), arr(st2), arr(flags), n, waves, shared, out, 1024)
+    assert rc == 0, rc
+    o = list(out)
+    M, W = o[6], o[7]
+    d = {"grid": o[0], "items": o[1], "ncls": o[2], "items0": o[3], "span": o[4], "mask": o[5], "cls": []}
+    pos = 8
+    for _ in range(2):
+        lg, rg = o[pos], o[pos + 1]
+        ents = [[(o[pos + 2 + 2 * (m * W + w)] & 0xffffffff, o[pos + 3 + 2 * (m * W + w)] & 0xffffffff) for w in range(W)] for m in range(M)]
+        d["cls"].append({"lg": lg, "rg": rg, "w": ents})
+        pos += 2 + 2 * M * W
+    d["jobs"] = [dict(cls=o[pos + 4 * j], vrow0=o[pos + 4 * j + 1], end=o[pos + 4 * j + 2], sk=o[pos + 4 * j + 3]) for j in range(n)]
+    return d
+
+
+def _check_plan(d, rows, st1, st2, waves):
+    """every step of every live row of every job exactly once; runs of a row are consecutive waves with one lead; <= 2 workgroups
+    per row; -> steps of the busiest SIMD"""
+    busiest = 0
+    for c in range(d["ncls"]):
+        pl = d["cls"][c]
+        G, rg = 1 << pl["lg"], pl["rg"]
+        jobs = [j for j in range(len(rows)) if d["jobs"][j]["cls"] == c]
+        s1, s2 = st1[jobs[0]], st2[jobs[0]]
+        cover = {}
+        owners = {}
+        for m in range(G):
+            simd = [0, 0, 0, 0]
+            w = 0
+            while w < waves:
+                a, b = pl["w"][m][w]
+                if not (a >> 16) & 1:
+                    w += 1
+                    continue
+                assert (a >> 9) & 1, "a run starts with its lead"
+                run = (a >> 11) & 31
+                assert run >= 1
+                for q in range(run):
+                    a2, b2 = pl["w"][m][w + q]
+                    assert (a2 >> 16) & 1 and (a2 & 255) == (a & 255) and ((a2 >> 9) & 1) == (q == 0)
+                    row, stream, s0, ns = a2 & 255, (a2 >> 8) & 1, b2 & 0xffff, b2 >> 16
+                    assert ns >= 1 and s0 + ns <= (s2 if stream else s1)
+                    for s_ in range(s0, s0 + ns):
+                        key = (row, stream, s_)
+                        assert key not in cover
+                        cover[key] = m
+                    owners.setdefault(row, set()).add(m)
+                    simd[(w + q) % 4] += ns
+                    assert ((a2 >> 10) & 1) == ((a >> 10) & 1)
+                w += run
+            busiest = max(busiest, max(simd))
+        assert len(cover) == rg * (s1 + s2), (len(cover), rg, s1, s2)
+        for row, ms in owners.items():
+            assert len(ms) <= 2
+            shared = any((a >> 10) & 1 for m in range(G) for a, b in pl["w"][m] if (a >> 16) & 1 and (a & 255) == row)
+            assert shared == (len(ms) == 2)
+        # the jobs' virtual rows tile the class's row space
+        pos = 0
+        for j in jobs:
+            assert d["jobs"][j]["vrow0"] == pos and d["jobs"][j]["end"] >= pos + rows[j]
+            if d["span"]:
+                assert d["jobs"][j]["end"] == pos + rows[j]
+            else:
+                assert d["jobs"][j]["end"] % rg == 0
+            pos = d["jobs"][j]["end"]
+    assert d["items"] == sum((max(d["jobs"][j]["end"] for j in range(len(rows)) if d["jobs"][j]["cls"] == c) + d["cls"][c]["rg"] - 1)
+                             // d["cls"][c]["rg"] << d["cls"][c]["lg"] for c in range(d["ncls"]))
+    assert d["grid"] == min(d["items"], 256)
+    return busiest
+
+
+def test_gemv_launch_planner_tables():
+    """The host-side launch planner of the fused GEMV (csrc/qpal_capi.hip plan_launch, C-ABI qpal_plan_gemv): its per-wave tables
+    cover every step of every row exactly once for the shapes the workloads launch, keep to two workgroups per row, and reach the
+    balance the design claims — Llama-8B q|k|v (three jobs, 192 rows of 16 + 16 steps) on 256 workgroups with 6 steps on the
+    busiest SIMD (whole rows: 8), gate|up on 256 with 28, o and down split in two."""
+    Z = 1  # outputs declared zeroed
+    # q | k | v of Llama-3.1-8B, tcomb: groups span the three jobs
+    rows, s1, s2 = [128, 32, 32], [16] * 3, [16] * 3
+    d = _plan(rows, s1, s2, [Z] * 3)
+    assert d["span"] == 1 and d["grid"] == 256 and (1 << d["cls"][0]["lg"], d["cls"][0]["rg"]) == (4, 3)
+    assert _check_plan(d, rows, s1, s2, 16) == 6
+    assert all(j["sk"] == 2 for j in d["jobs"])
+    # ... not zeroed: no shared rows without a large gain (a memset node costs more than two steps)
+    d = _plan(rows, s1, s2, [0] * 3)
+    assert _check_plan(d, rows, s1, s2, 16) == 8 and all(j["sk"] == 1 for j in d["jobs"]) and d["grid"] == 192
+    # ... jobs that do not share x: groups stay inside their job (padded virtual rows)
+    d = _plan(rows, s1, s2, [Z] * 3, shared=0)
+    assert d["span"] == 0 and _check_plan(d, rows, s1, s2, 16) <= 8
+    # o_proj, gate | up, down_proj
+    for rows, s1, s2, want_grid, want_busy in (([128], [16], [16], 256, 4), ([448, 448], [16, 16], [16, 16], 256, 28),
+                                                ([128], [56], [56], 256, 14), ([128], [32], [0], 256, 4), ([448, 448], [32, 32], [0, 0], 256, 28)):
+        d = _plan(rows, s1, s2, [Z] * len(rows))
+        assert d["grid"] == want_grid, (rows, d["grid"])
+        assert _check_plan(d, rows, s1, s2, 16) == want_busy, rows
+    # Llama-3.1-70B shapes (k = 8192: 64 steps; down: k = 28672): one round, balanced within a step of the ideal
+    for rows, st in (([256, 32, 32], 64), ([256], 64), ([896, 896], 64), ([256], 224)):
+        d = _plan(rows, [st] * len(rows), [0] * len(rows), [Z] * len(rows))
+        ideal = -(-sum(rows) * st // 1024)
+        busy = _check_plan(d, rows, [st] * len(rows), [0] * len(rows), 16)
+        assert d["items"] <= 256 and ideal <= busy <= ideal + max(2, ideal // 8), (rows, st, busy, ideal)
+    # two geometry classes in one launch (any-KV: single- and two-stream jobs), odd shapes, 8-wave workgroups
+    rows, s1, s2 = [128, 32, 32], [32, 16, 32], [0, 16, 0]
+    d = _plan(rows, s1, s2, [Z] * 3)
+    assert d["ncls"] == 2 and d["mask"] == 0b010 and d["span"] == 0
+    _check_plan(d, rows, s1, s2, 16)
+    for rows, st1_, st2_, waves in (([7], [5], [0], 16), ([3, 1000], [9, 9], [4, 4], 16), ([33], [1], [1], 16), ([64], [32], [32], 8),
+                                    ([1], [448], [0], 16), ([2000], [2], [0], 16)):
+        d = _plan(rows, st1_, st2_, [Z] * len(rows), waves=waves)
+        _check_plan(d, rows, st1_, st2_, waves)
+    # the SwiGLU epilogue: whole rows, a power-of-two count per workgroup, the up row's lead marked
+    d = _plan([896], [16], [16], [4 | Z])
+    pl = d["cls"][0]
+    assert pl["lg"] == 0 and pl["rg"] in (2, 4, 8, 16) and all(j["sk"] == 1 for j in d["jobs"])
+    leads = [(a & 255, (a >> 17) & 1) for a, b in pl["w"][0] if (a >> 9) & 1]
+    assert leads and all(flag == (1 - row % 2) for row, flag in leads)

@@ -855,7 +855,7 @@ def test_pair_mode_rows_shared_by_two_workgroups(qp, oracle, qstr, m, k):
         qp.multi_gemv(mods, x.cuda(), outs=acc, accumulate=True)
         for a, r, p_ in zip(acc, res, plain):
             assert torch.allclose(a, r + p_, rtol=1e-4, atol=1e-4 * float(p_.abs().max()))
-    # the planner really paired these launches (its log line says so), and QPAL_PAIR=0 does not
+    # the planner really let workgroups share rows in these launches (its log line says so), and QPAL_PAIR=0 (QPAL_SHARE=0) does not
     code = textwrap.dedent(f"""
         import torch, qpalette_amd as qp
         infos = [qp.mem_op.dummy_linear_info({k}, {m}, "{qstr}", seed=70 + i, codebook_seed=13) for i in range(2)]
@@ -871,7 +871,7 @@ def test_pair_mode_rows_shared_by_two_workgroups(qp, oracle, qstr, m, k):
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-1500:]
         lines = [l for l in r.stderr.splitlines() if l.startswith("[qpal plan]")]
-        assert lines and (" pair " in lines[-1]) == want, lines
+        assert lines and ("shared rows" in lines[-1]) == want, lines
 
 
 def test_lane_xor_forms_match_the_shuffle(tmp_path):
