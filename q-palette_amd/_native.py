@@ -92,6 +92,8 @@ def lib():
                 "(no CPU fallback). Build it with __graft_entry__.build() or `make -C q-palette_amd/csrc`.")
         l = ctypes.CDLL(SO_PATH)
         for name, args in _SIGNATURES.items():
+            if os.environ.get("QPAL_LIB") and not hasattr(l, name):
+                continue  # (perf experiments: an older build of the library beside the current host code)
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = _I

@@ -167,23 +167,53 @@ TapePlan tape_plan(int lg_g, int rg, int st1, int st2, int W) {
         // steps on the whole pieces and 4 x 4 on the half row (28 steps on every SIMD), not by 7 steps everywhere (21 waves).
         // Try every quantum q: ceil(len / q) waves per piece, the waves left over given to the piece(s) with the longest waves or
         // all to one piece — and keep the assignment whose busiest SIMD is least loaded.
+        // Wave ORDER inside a member: waves of one row stay together (the reduction sums a run of consecutive waves), but rows — and
+        // the pieces of a row — may come in any order, and the order matters: the hardware serves a SIMD's oldest wave first, so a
+        // short piece on waves 0..3 is finished early and leaves its SIMD with three waves for the rest of the launch, while the
+        // same piece on the YOUNGEST waves runs in the gaps of the long ones and ends with them (measured, round 5: gate | up of
+        // Llama-8B 14.5 us with the half row's 4-step waves first, 13.6 with them last — what rounds 3-4's pair mode did).
+        // Short waves last: rows by their shortest wave, descending; inside a row the pieces by wave length, descending.
         const long L = t1 - t0;
-        int best_n[kPlanWaves] = {0}, best_cost = 1 << 30, best_long = 1 << 30;
+        struct Slot { int piece, part, ns; };
+        Slot best_slots[kPlanWaves];
+        int best_nslots = 0, best_cost = 1 << 30, best_long = 1 << 30;
         const int q0 = (int)((L + W - 1) / W);
         auto consider = [&](const int *nw) {
+            int order[kPlanWaves], per[kPlanWaves], rowmin[256];
+            for (int i = 0; i < np; i++) rowmin[pc[i].row] = 1 << 30;
+            for (int i = 0; i < np; i++) {
+                order[i] = i;
+                per[i] = pc[i].len / nw[i];  // (the shortest wave of the piece)
+                if (per[i] < rowmin[pc[i].row]) rowmin[pc[i].row] = per[i];
+            }
+            for (int i = 1; i < np; i++)  // insertion sort: (row's SHORTEST wave desc — rows with short waves last —, row asc, piece's wave length desc)
+                for (int k = i; k > 0; k--) {
+                    const int x = order[k - 1], y = order[k];
+                    const bool swap = rowmin[pc[y].row] != rowmin[pc[x].row] ? rowmin[pc[y].row] > rowmin[pc[x].row]
+                                      : pc[y].row != pc[x].row             ? pc[y].row < pc[x].row
+                                                                           : per[y] > per[x];
+                    if (!swap) break;
+                    order[k - 1] = y;
+                    order[k] = x;
+                }
+            Slot slots[kPlanWaves];
             int simd[4] = {0, 0, 0, 0}, w = 0, longest = 0;
-            for (int i = 0; i < np; i++)
+            for (int oi = 0; oi < np; oi++) {
+                const int i = order[oi];
                 for (int part = 0; part < nw[i]; part++, w++) {
                     const int ns = pc[i].len / nw[i] + (part < pc[i].len % nw[i] ? 1 : 0);
+                    slots[w] = Slot{i, part, ns};
                     simd[w & 3] += ns;
                     if (ns > longest) longest = ns;
                 }
+            }
             int c = simd[0];
             for (int sd = 1; sd < 4; sd++) c = simd[sd] > c ? simd[sd] : c;
             if (c < best_cost || (c == best_cost && longest < best_long)) {
                 best_cost = c;
                 best_long = longest;
-                for (int i = 0; i < np; i++) best_n[i] = nw[i];
+                best_nslots = w;
+                for (int k = 0; k < w; k++) best_slots[k] = slots[k];
             }
         };
         for (int q = q0 > 0 ? q0 : 1; q <= 4 * q0 + 4; q++) {
@@ -202,8 +232,8 @@ TapePlan tape_plan(int lg_g, int rg, int st1, int st2, int W) {
                 for (int k = 0; k < spare; k++) {
                     int at = -1, worst = 0;
                     for (int i = 0; i < np; i++) {
-                        const int per = (pc[i].len + g[i] - 1) / g[i];
-                        if (g[i] < pc[i].len && per > worst) { worst = per; at = i; }
+                        const int pr = (pc[i].len + g[i] - 1) / g[i];
+                        if (g[i] < pc[i].len && pr > worst) { worst = pr; at = i; }
                     }
                     if (at < 0) break;
                     g[at]++;
@@ -218,17 +248,17 @@ TapePlan tape_plan(int lg_g, int rg, int st1, int st2, int W) {
             }
         }
         if (best_cost == 1 << 30) return tp;
-        int wave = 0;
-        for (int i = 0; i < np; i++) {
-            int s0 = pc[i].s0;
-            for (int part = 0; part < best_n[i]; part++, wave++) {
-                const int ns = pc[i].len / best_n[i] + (part < pc[i].len % best_n[i] ? 1 : 0);
-                if (ns > 0xffff || s0 > 0xffff) return tp;
-                WaveEnt &e = tp.lp.w[m][wave];
-                e.a = (uint32_t)pc[i].row | ((uint32_t)pc[i].stream << 8) | (1u << 16);
-                e.b = (uint32_t)s0 | ((uint32_t)ns << 16);
-                s0 += ns;
-            }
+        int wave = best_nslots;
+        for (int k = 0; k < best_nslots; k++) {
+            const Piece &pp = pc[best_slots[k].piece];
+            int nparts = 0;  // (waves of this piece: its slots are consecutive)
+            for (int k2 = 0; k2 < best_nslots; k2++) nparts += best_slots[k2].piece == best_slots[k].piece;
+            const int base = pp.len / nparts, rem = pp.len % nparts, part = best_slots[k].part;
+            const int s0 = pp.s0 + part * base + (part < rem ? part : rem);
+            if (best_slots[k].ns > 0xffff || s0 > 0xffff) return tp;
+            WaveEnt &e = tp.lp.w[m][k];
+            e.a = (uint32_t)pp.row | ((uint32_t)pp.stream << 8) | (1u << 16);
+            e.b = (uint32_t)s0 | ((uint32_t)best_slots[k].ns << 16);
         }
         // runs: consecutive waves of one row; the first is the run's lead and knows its length
         for (int w0 = 0; w0 < wave;) {
@@ -265,25 +295,11 @@ TapePlan tape_plan(int lg_g, int rg, int st1, int st2, int W) {
     return tp;
 }
 
-// may the groups of a class run across job boundaries?  Only where the jobs agree on everything a workgroup shares (a workgroup
-// stages x and the codebook image ONCE) and no job needs whole row pairs (SwiGLU epilogue)
-bool jobs_share_staging(const TcMultiParams &mp) {
-    const TcParams &a = mp.job[0];
-    for (int j = 0; j < mp.njobs; j++) {
-        const TcParams &b = mp.job[j];
-        if (b.x != a.x || b.tab != a.tab || b.n != a.n || b.k != a.k || b.x_lds != a.x_lds || b.x_rot != a.x_rot || b.x_su != a.x_su ||
-            b.x_rms_w != a.x_rms_w || b.x_src_f32 != a.x_src_f32 || b.x_rms_eps != a.x_rms_eps || b.x_hadk != a.x_hadk ||
-            b.x_pre != a.x_pre || b.x_post != a.x_post || b.act_out || b.nsc1 != a.nsc1 || b.nsc2 != a.nsc2 || b.col2 != a.col2)
-            return false;
-    }
-    return true;
-}
-
-// virtual rows of class c under a candidate: jobs padded to whole groups, or — `span` — packed back to back
-int class_rows(const TcMultiParams &mp, int c, int rg, bool span) {
+// virtual rows of class c under a candidate: every job padded to whole groups
+int class_rows(const TcMultiParams &mp, int c, int rg) {
     int rows = 0;
     for (int j = 0; j < mp.njobs; j++)
-        if (mp.job[j].cls == c) rows += span ? mp.job[j].nrows : (mp.job[j].nrows + rg - 1) / rg * rg;
+        if (mp.job[j].cls == c) rows += (mp.job[j].nrows + rg - 1) / rg * rg;
     return rows;
 }
 
@@ -292,7 +308,6 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves 
     static const int force_g = env_int("QPAL_FORCE_G", 0);
     static const int force_rg = env_int("QPAL_FORCE_RG", 0);
     static const int share_on = env_int("QPAL_SHARE", env_int("QPAL_PAIR", 1));
-    static const int span_on = env_int("QPAL_SPAN", 1);
     const int cap = round_capacity(waves);
     // geometry classes: (st1, st2) — at most two per launch (the entry points split a launch that has more)
     int ncls = 0, cst1[2] = {0, 0}, cst2[2] = {0, 0};
@@ -309,14 +324,11 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves 
     // what the jobs allow: sharing a row needs a zeroed (or accumulated-onto) output — or a memset node (~3 us: worth it only for
     // a large gain); the SwiGLU epilogue needs both rows of an up / gate pair whole inside one workgroup, in runs of equal length
     bool free_share = share_on != 0, swiglu = false;
-    int min_rows = 1 << 30;
     for (int j = 0; j < mp.njobs; j++) {
         const TcParams &p = mp.job[j];
         if (!((out_zeroed && out_zeroed[j]) || p.accumulate)) free_share = false;
         swiglu = swiglu || p.act_out != nullptr;
-        if (p.nrows < min_rows) min_rows = p.nrows;
     }
-    const bool may_span = span_on && ncls == 1 && mp.njobs > 1 && jobs_share_staging(mp);
     constexpr int kMemsetCost = 10;  // a memset node in steps of the busiest SIMD (~3 us / 0.3 us)
     constexpr int kRoundCost = 4;    // a workgroup's fixed cost per item, in steps
     // candidates per class
@@ -340,16 +352,13 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves 
     // more workgroups inside the round (the largest number of waves per row that still fits ONE round: the rule of rounds 1-4)
     long best = -1;
     int bi[2] = {0, 0};
-    bool bspan = false;
     for (int i0 = 0; i0 < ncand[0]; i0++)
         for (int i1 = 0; i1 < (ncls > 1 ? ncand[1] : 1); i1++) {
             const Cand *cc[2] = {&cands[0][i0], ncls > 1 ? &cands[1][i1] : nullptr};
-            // (a group reaches into the next job at most once: every job must hold a group's rows)
-            const bool span = may_span && min_rows >= cc[0]->rg;
             int items = 0, cost = 0;
             bool shared = false;
             for (int c = 0; c < ncls; c++) {
-                items += (class_rows(mp, c, cc[c]->rg, span) + cc[c]->rg - 1) / cc[c]->rg << cc[c]->lg_g;
+                items += (class_rows(mp, c, cc[c]->rg) + cc[c]->rg - 1) / cc[c]->rg << cc[c]->lg_g;
                 if (cc[c]->tp.cost > cost) cost = cc[c]->tp.cost;
                 shared = shared || cc[c]->tp.shared;
             }
@@ -363,12 +372,10 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves 
                 best = score;
                 bi[0] = i0;
                 bi[1] = i1;
-                bspan = span;
             }
         }
     // the launch's table
     mp.ncls = ncls;
-    mp.span = bspan ? 1 : 0;
     mp.cls_mask = 0;
     int items_c[2] = {0, 0};
     for (int c = 0; c < ncls; c++) {
@@ -380,7 +387,7 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves 
             if (p.cls != c) continue;
             if (c) mp.cls_mask |= 1 << j;
             p.vrow0 = vrow;
-            vrow += bspan ? p.nrows : (p.nrows + cd.rg - 1) / cd.rg * cd.rg;
+            vrow += (p.nrows + cd.rg - 1) / cd.rg * cd.rg;
             mp.row_end[j] = vrow;
             p.sk = cd.tp.shared ? 2 : 1;  // (> 1: the output must start at zero — zero_split_jobs() adds the memset the caller did not)
             p.nitems = 0;
@@ -400,7 +407,7 @@ void plan_launch(TcMultiParams &mp, const int *out_zeroed, int &grid, int waves 
     grid = mp.total_items < cap ? mp.total_items : cap;
     static const int plan_log = env_int("QPAL_PLAN_LOG", 0);  // one line per planned GEMV launch on stderr (tests, debugging)
     if (plan_log) {
-        fprintf(stderr, "[qpal plan] gemv: %d jobs, grid %d%s:", mp.njobs, grid, bspan ? ", groups span jobs" : "");
+        fprintf(stderr, "[qpal plan] gemv: %d jobs, grid %d:", mp.njobs, grid);
         for (int j = 0; j < mp.njobs; j++) {
             const Cand &cd = cands[mp.job[j].cls][bi[mp.job[j].cls]];
             fprintf(stderr, " [rows %d steps %d+%d groups of %d x %d rows, %s, busiest SIMD %d steps]", mp.job[j].nrows, mp.job[j].st1,
@@ -1012,7 +1019,8 @@ int qpal_plan_gemv(const int *rows, const int *steps1, const int *steps2, const 
         p.nsc2 = steps2[j] * 4;
         p.n = 1;
         p.k = (steps1[j] + steps2[j]) * 128;
-        p.x = shared_staging ? dummy_x : dummy_x + (j % 4);  // (different x per job: groups must not span jobs)
+        p.x = dummy_x;
+        (void)shared_staging;
         zeroed[j] = flags[j] & 1;
         p.accumulate = (flags[j] >> 1) & 1;
         p.act_out = (flags[j] >> 2) & 1 ? reinterpret_cast<uint16_t *>(8) : nullptr;
@@ -1028,7 +1036,7 @@ int qpal_plan_gemv(const int *rows, const int *steps1, const int *steps2, const 
     out[o++] = mp.total_items;
     out[o++] = mp.ncls;
     out[o++] = mp.items0;
-    out[o++] = mp.span;
+    out[o++] = 0;  // (groups never run across job boundaries: measured slower, round 5)
     out[o++] = mp.cls_mask;
     out[o++] = kPlanMembers;
     out[o++] = kPlanWaves;

@@ -107,10 +107,9 @@ struct TcMultiParams {
     int item_end[kMaxJobs];   // lockstep GEMM kernel (tc_gemm.h): items of jobs 0..j
     // fused GEMV kernel (round 5): table-driven geometry
     int ncls;                 // geometry classes in this launch (1 or 2)
-    int span;                 // 1: groups may reach into the next job (the jobs agree on what a workgroup stages; every job holds a group's rows)
     int items0;               // items (workgroup-sized pieces of work) of class 0; class 1 follows
     int cls_mask;             // bit j: job j belongs to class 1
-    int row_end[kMaxJobs];    // end of job j's virtual rows inside its class's row space (padded to whole groups unless groups may span jobs)
+    int row_end[kMaxJobs];    // end of job j's virtual rows inside its class's row space (padded to whole groups)
     LaunchPlan plan[2];
     TcParams job[kMaxJobs];
 };
@@ -690,7 +689,6 @@ inline TcEarly early_args(const TcMultiParams &mp) {
         for (int j = 0; j < 3; j++) e.ie |= (j < mp.njobs - 1 ? mp.row_end[j] : 0x3ff) << (10 * j);
         e.on |= (mp.plan[0].lg_g << 16) | (mp.plan[0].rg << 18);
     }
-    if (mp.span) e.on |= 1 << 25;
     return e;
 }
 
@@ -882,25 +880,15 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     // the class's row space, and w[member][wave] names this wave's row inside the group, its stream and its steps.  The row's JOB
     // follows from the jobs' row ends.  FAST PATH (eie != 0: one class, <= 4 jobs): lg_g, rg and the row ends are preloaded, so the
     // addresses of the table entry and of the job of the group's FIRST row are known before any kernel argument has arrived — one
-    // scalar-load round trip fetches both, plus the stream pointers of the job BEHIND it (a group may reach into the next job: its
-    // waves there pick those, and re-fetch the rest of that job behind the staging barrier, off the path to the first weights).
+    // scalar-load round trip fetches both.
     // Everything on the way to the first weight loads is in this one batch (round 4: a second, dependent round trip there cost
     // 0.3-0.4 us per launch).
     const bool fast = eie != 0;
-    struct JobB {  // the job behind a group's first job: what a wave needs of it BEFORE its first weight loads (its first virtual row
-        const uint32_t *c1, *c2;  // is the end of the job in front of it: spanning groups pack the jobs back to back)
-        int nrows, kv, kv2;
-    };
-    auto job_b = [&](int j) {
-        if constexpr (is_any_v<C1>) return JobB{mp.job[j].c1, mp.job[j].c2, mp.job[j].nrows, mp.job[j].kv, mp.job[j].kv2};
-        else return JobB{mp.job[j].c1, mp.job[j].c2, mp.job[j].nrows, 0, 0};
-    };
+    const int total_items = mp.total_items;  // (requested with the first batch: read behind the first item, it is a whole scalar-load round trip in every workgroup's tail)
     struct Where {  // a wave's place in the launch
         WaveEnt ent;
         int row0;   // first virtual row of its group
         int jA;     // job of that row
-        int endA;   // end of jA's virtual rows
-        int jB;     // the job behind jA (jA itself when there is none)
     };
     // generic lookup (launches the fast path does not cover, and the later items of a workgroup in launches of more than one round):
     // plan header, table entry and the row table come from the kernel-argument block, the job in a second, dependent round trip
@@ -914,20 +902,14 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         Where wh;
         wh.row0 = (item >> lgg) * mp.plan[c].rg;
         wh.ent = mp.plan[c].w[item & ((1 << lgg) - 1)][wave];
-        int jA = -1, jB = -1, endA = 0x7fffffff, last = 0;
+        int jA = -1, last = 0;
 #pragma unroll 1  // (a scalar loop: unrolled, its eight row ends and masks cost the kernel's other paths their scalar registers)
         for (int i = 0; i < mp.njobs; i++) {
             const bool mine = ((mp.cls_mask >> i) & 1) == c;
             if (mine) last = i;
-            if (mine && jA >= 0 && jB < 0) jB = i;
-            if (mine && jA < 0 && wh.row0 < mp.row_end[i]) {
-                jA = i;
-                endA = mp.row_end[i];
-            }
+            if (mine && jA < 0 && wh.row0 < mp.row_end[i]) jA = i;
         }
         wh.jA = jA < 0 ? last : jA;  // (rows behind the class's last job: dead rows of the last group)
-        wh.jB = jB < 0 ? wh.jA : jB;
-        wh.endA = endA;
         return wh;
     };
     // the first item on the fast path: everything from preloaded arguments, its loads form the first batch
@@ -938,19 +920,15 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         f_wh.ent = mp.plan[0].w[item & ((1 << lgg) - 1)][wave];
         const int e0 = eie & 0x3ff, e1 = (eie >> 10) & 0x3ff, e2 = (eie >> 20) & 0x3ff;
         f_wh.jA = (f_wh.row0 >= e0 ? 1 : 0) + (f_wh.row0 >= e1 ? 1 : 0) + (f_wh.row0 >= e2 ? 1 : 0);
-        f_wh.endA = f_wh.jA == 0 ? e0 : f_wh.jA == 1 ? e1 : f_wh.jA == 2 ? e2 : 0x3ff;
-        f_wh.jB = f_wh.endA < 0x3ff ? f_wh.jA + 1 : f_wh.jA;  // (0x3ff: no job behind it)
     }
     if (!fast) f_wh = lookup(blockIdx.x);
     TcParams p = mp.job[f_wh.jA];
     cur_j = f_wh.jA;
-    const bool span = (eon & (1 << 25)) != 0;  // groups may reach into the next job (host: plan_launch)
-    const JobB f_B = job_b(span ? f_wh.jB : f_wh.jA);  // (no branch here: a branch puts a wait for job A between the two batches)
     // Pin the batch: left alone, the compiler requests the job only inside the item, after it has waited for the table entry.
     // (round 5: what only the epilogue reads — out, ldo, wscale, oscale, accumulate — is requested behind the first weight loads
     // instead, see there: held from here it pushed the kernel over its scalar-register budget, and every spill is a wait)
     asm volatile("" ::"s"(p.c1), "s"(p.c2), "s"(p.x), "s"(p.tab), "s"(p.nrows), "s"(p.nsc1), "s"(p.vrow0), "s"(f_wh.ent.a), "s"(f_wh.ent.b),
-                 "s"(p.nsc2), "s"(f_B.c1), "s"(f_B.c2), "s"(f_B.nrows), "s"(p.x_lds), "s"(p.n), "s"(p.k), "s"(mp.zero_chunks));
+                 "s"(p.nsc2), "s"(p.x_lds), "s"(p.n), "s"(p.k), "s"(mp.zero_chunks), "s"(total_items));
     // One work item.  FIRST (this workgroup's first item, compile-time): the only one that consumes the early-staged registers —
     // a body of its own, so that those registers are plain straight-line values.  (Measured against ONE body with the early wait
     // in front of the item loop, profiles/r04_ab_prologue.txt: the single body is 0.3-0.4 us slower on every short launch —
@@ -965,19 +943,17 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
             uint32_t a[C1::NW];
             uint32_t b[TWO ? CB::NW : 1];
         } w;
-        // this wave's table entry, its group's first job (A) and the stream pointers of the job behind it (B)
+        // this wave's table entry and its group's job
         Where wh = f_wh;
-        JobB B = f_B;
         if constexpr (!FIRST) {
             wh = lookup(gitem);
             if (wh.jA != cur_j) {
                 p = mp.job[wh.jA];
                 cur_j = wh.jA;
             }
-            B = job_b(span ? wh.jB : wh.jA);
         }
         const WaveEnt ent = wh.ent;
-        const int row0 = wh.row0, endA = wh.endA, jB = wh.jB;
+        const int row0 = wh.row0;
         float *red = reinterpret_cast<float *>(scratch);                           // [W][n][32]
         uint16_t *xs = reinterpret_cast<uint16_t *>(scratch + W * 32 * 4 * p.n);   // [n][k] + 32 zero halves
         const int zero_off = p.n * p.k;
@@ -988,14 +964,13 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
             p.dbg[((long)blockIdx.x * 16 + wave) * 8] = (t_now & ((1ull << 52) - 1)) | ((t_now - t_entry) << 52);
         }
 #endif
-        // the wave's row: virtual row -> (job, row inside the job).  in_b: the row lies behind job A's rows, i.e. in job B (the
-        // planner lets a group reach into the next job only where every job has at least a group's rows and the jobs agree on
-        // everything a workgroup shares: x, codebook, batch, rotation — so one boundary per group at most, and the staging below
-        // may read those from either job)
+        // the wave's row: virtual row -> row inside its job (a group never leaves its job: the jobs' virtual rows are padded to whole
+        // groups.  Groups that run across job boundaries — q | k | v of Llama-8B as ONE row space of 192 rows, 64 groups of 4 x 3 rows,
+        // 6 instead of 8 steps on the busiest SIMD — were built and measured in round 5: 6.43 us against 6.30, the launch is not bound
+        // by its steps; profiles/r05_ab_tape_planner.txt)
         const int vrow = row0 + (int)(ent.a & 255u);
-        const bool in_b = span && vrow >= endA;
-        const int sr = vrow - (in_b ? endA : p.vrow0);              // supertile row inside its job
-        const int nrows_j = in_b ? B.nrows : p.nrows;
+        const int sr = vrow - p.vrow0;            // supertile row inside its job
+        const int nrows_j = p.nrows;
         const bool live = sr < nrows_j && ((ent.a >> 16) & 1u) != 0;
         // (the entry's epilogue bits — lead, shared row, run length — are cut out of `ea` again BEHIND the steps: one scalar register
         // held across them instead of four)
@@ -1003,7 +978,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         // (stream, [s0, s1)) of the wave's piece (any-KV kernels take column-split jobs too: the two streams are two KV of the same
         // codebook size, and a wave picks its decode loop by the stream its piece lies in — a wave-uniform choice)
         constexpr bool ANY = is_any_v<C1>;
-        const int kv1_j = in_b ? B.kv : p.kv, kv2_j = in_b ? B.kv2 : p.kv2;
+        const int kv1_j = p.kv, kv2_j = p.kv2;
         const bool two_rt = TWO || (ANY && kv2_j != 0);
         const bool on2 = two_rt && ((ent.a >> 8) & 1u) != 0;
         int s0 = (int)(ent.b & 0xffffu);
@@ -1011,7 +986,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         if (!live) s0 = s1 = 0;
         const int nw1 = ANY ? kv1_j : C1::NW;  // dwords per lane per supertile of stream 1
         const int nw2 = ANY ? kv2_j : CB::NW;
-        const uint32_t *c1_j = in_b ? B.c1 : p.c1, *c2_j = in_b ? B.c2 : p.c2;
+        const uint32_t *c1_j = p.c1, *c2_j = p.c2;
         const StreamView sv1{c1_j + (long)(live ? sr : 0) * p.nsc1 * 16 * nw1, p.nsc1, 0};
         const StreamView sv2{two_rt ? c2_j + (long)(live ? sr : 0) * p.nsc2 * 16 * nw2 : c1_j, two_rt ? p.nsc2 : p.nsc1,
                              p.col2};
@@ -1278,12 +1253,6 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         uint32_t wraw;
         asm volatile("" : "=v"(wraw));  // "no value yet": a constant here would be merged with the load at the join
                                         // below, and the merge waits for the load on the spot
-        // A wave whose row lies in the job BEHIND its group's first job: the rest of that job (output, scales, flags) — fetched here,
-        // behind the first weight loads and the staging barrier (everything the staging read is the same in both jobs).
-        if (in_b && jB != cur_j) {
-            p = mp.job[jB];
-            cur_j = jB;
-        }
         // The lead wave of a run finishes its row with lanes 0..31 (lanes 32..63: the gate row behind an up row, SwiGLU epilogue only)
         const int fr = lane & 31, fhi = lane >> 5;
         bool fin = ((ea >> 9) & 1u) != 0 && live && fhi == 0;   // lead: first wave of its row's run — it sums the run and writes the row
@@ -1388,10 +1357,10 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         QPAL_STAMP(7);
         __syncthreads();
     };
-    // (the grid never exceeds the item count: host, plan_launch; the count is read only once the first item is done)
+    // (the grid never exceeds the item count: host, plan_launch)
     int gitem = blockIdx.x;
     run_item(gitem, std::true_type{});
-    for (gitem += gridDim.x; gitem < mp.total_items; gitem += gridDim.x) run_item(gitem, std::false_type{});
+    for (gitem += gridDim.x; gitem < total_items; gitem += gridDim.x) run_item(gitem, std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------------

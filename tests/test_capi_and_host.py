@@ -397,18 +397,19 @@ def test_gemv_launch_planner_tables():
     balance the design claims — Llama-8B q|k|v (three jobs, 192 rows of 16 + 16 steps) on 256 workgroups with 6 steps on the
     busiest SIMD (whole rows: 8), gate|up on 256 with 28, o and down split in two."""
     Z = 1  # outputs declared zeroed
-    # q | k | v of Llama-3.1-8B, tcomb: groups span the three jobs
+    # q | k | v of Llama-3.1-8B, tcomb: three jobs, groups stay inside their job.  (192 rows x 32 steps are exactly 24 steps for each
+    # of 256 workgroups, but only as ONE row space of groups of 4 x 3 rows that run across the jobs' boundaries — built and measured
+    # in round 5: 6 instead of 8 steps on the busiest SIMD, and the launch 0.13 us SLOWER: it is not bound by its steps.)
     rows, s1, s2 = [128, 32, 32], [16] * 3, [16] * 3
     d = _plan(rows, s1, s2, [Z] * 3)
-    assert d["span"] == 1 and d["grid"] == 256 and (1 << d["cls"][0]["lg"], d["cls"][0]["rg"]) == (4, 3)
-    assert _check_plan(d, rows, s1, s2, 16) == 6
-    assert all(j["sk"] == 2 for j in d["jobs"])
+    assert d["span"] == 0 and d["grid"] == 192 and _check_plan(d, rows, s1, s2, 16) == 8
+    # ... one fused q|k|v job of 192 rows does get there: groups of 4 workgroups x 3 rows, 6 steps on the busiest SIMD
+    d = _plan([192], [16], [16], [Z])
+    assert d["grid"] == 256 and (1 << d["cls"][0]["lg"], d["cls"][0]["rg"]) == (4, 3) and _check_plan(d, [192], [16], [16], 16) == 6
+    assert d["jobs"][0]["sk"] == 2
     # ... not zeroed: no shared rows without a large gain (a memset node costs more than two steps)
-    d = _plan(rows, s1, s2, [0] * 3)
-    assert _check_plan(d, rows, s1, s2, 16) == 8 and all(j["sk"] == 1 for j in d["jobs"]) and d["grid"] == 192
-    # ... jobs that do not share x: groups stay inside their job (padded virtual rows)
-    d = _plan(rows, s1, s2, [Z] * 3, shared=0)
-    assert d["span"] == 0 and _check_plan(d, rows, s1, s2, 16) <= 8
+    d = _plan([192], [16], [16], [0])
+    assert _check_plan(d, [192], [16], [16], 16) == 8 and d["jobs"][0]["sk"] == 1 and d["grid"] == 192
     # o_proj, gate | up, down_proj
     for rows, s1, s2, want_grid, want_busy in (([128], [16], [16], 256, 4), ([448, 448], [16, 16], [16, 16], 256, 28),
                                                 ([128], [56], [56], 256, 14), ([128], [32], [0], 256, 4), ([448, 448], [32, 32], [0, 0], 256, 28)):
@@ -420,11 +421,11 @@ def test_gemv_launch_planner_tables():
         d = _plan(rows, [st] * len(rows), [0] * len(rows), [Z] * len(rows))
         ideal = -(-sum(rows) * st // 1024)
         busy = _check_plan(d, rows, [st] * len(rows), [0] * len(rows), 16)
-        assert d["items"] <= 256 and ideal <= busy <= ideal + max(2, ideal // 8), (rows, st, busy, ideal)
+        assert d["items"] <= 256 and ideal <= busy <= ideal + max(2, ideal // 8) + (2 if len(rows) > 1 else 0), (rows, st, busy, ideal)
     # two geometry classes in one launch (any-KV: single- and two-stream jobs), odd shapes, 8-wave workgroups
     rows, s1, s2 = [128, 32, 32], [32, 16, 32], [0, 16, 0]
     d = _plan(rows, s1, s2, [Z] * 3)
-    assert d["ncls"] == 2 and d["mask"] == 0b010 and d["span"] == 0
+    assert d["ncls"] == 2 and d["mask"] == 0b010
     _check_plan(d, rows, s1, s2, 16)
     for rows, st1_, st2_, waves in (([7], [5], [0], 16), ([3, 1000], [9, 9], [4, 4], 16), ([33], [1], [1], 16), ([64], [32], [32], 8),
                                     ([1], [448], [0], 16), ([2000], [2], [0], 16)):
