@@ -14,10 +14,11 @@ using namespace qpal;
 
 namespace {
 
-constexpr int kMaxBatch = 64;  // fused decode + GEMV / skinny GEMM: up to 8 MFMA column groups of 8 batch rows
+constexpr int kMaxBatch = 128;  // fused decode + skinny GEMM: up to 8 groups of 16 batch rows (tc_gemm16.h); the per-wave-K-chunk kernels: 64
 
-// MFMA column groups for a batch: 1, 2 (16 waves per workgroup), 4, 8 (8 waves: tc_kernels.h gemv_waves)
-int nbg_of(int n) { return n <= 8 ? 1 : n <= 16 ? 2 : n <= 32 ? 4 : 8; }
+// batch -> 8-row units the kernels are instantiated for: 1, 2 (16 waves per workgroup), 4, 8 (8 waves: tc_kernels.h gemv_waves);
+// 16 (batch 65..128): the lockstep kernel of tc_gemm16.h only
+int nbg_of(int n) { return n <= 8 ? 1 : n <= 16 ? 2 : n <= 32 ? 4 : n <= 64 ? 8 : 16; }
 int waves_of(int nbg) { return gemv_waves<1>() == 8 ? 8 : (nbg >= 4 ? 8 : 16); }
 // workgroups one launch round can hold: one per CU; two with the 8-wave experiment build (tc_kernels.h QPAL_W8), whose
 // batch <= 16 kernels leave room for a second workgroup's LDS and registers
@@ -490,7 +491,7 @@ int slice_gemm_batch(TcMultiParams &mp, int *ms, int *zeroed) {
            (force > 0 || groups * bs * 2 <= want_items))
         bs *= 2;
     if (bs == 1) return n;
-    const int rows = ((n + bs - 1) / bs + 7) & ~7;  // whole batch groups per slice
+    const int rows = ((n + bs - 1) / bs + 15) & ~15;  // whole groups of 16 batch rows per slice
     const TcMultiParams src = mp;
     int ms0[kMaxJobs], z0[kMaxJobs];
     for (int j = 0; j < kMaxJobs; j++) {
@@ -584,7 +585,8 @@ int launch_tcq_gemm(const TcMultiParams &mp, int S, int KV1, int KV2, int nbg, i
     return nbg == 1 ? launch_tcq_gemm_nbg1(mp, S, KV1, KV2, grid, stream)
          : nbg == 2 ? launch_tcq_gemm_nbg2(mp, S, KV1, KV2, grid, stream)
          : nbg == 4 ? launch_tcq_gemm_nbg4(mp, S, KV1, KV2, grid, stream)
-                    : launch_tcq_gemm_nbg8(mp, S, KV1, KV2, grid, stream);
+         : nbg == 8 ? launch_tcq_gemm_nbg8(mp, S, KV1, KV2, grid, stream)
+                    : launch_tcq_gemm_nbg16(mp, S, KV1, KV2, grid, stream);
 }
 
 // Zeroing of the split-K outputs of a multi-job launch: contiguous [n][m] outputs that follow each other in memory (how
@@ -633,6 +635,7 @@ int tcq_gemv_one(float *out, long ldo, const void *c1, const void *c2, const voi
         if (rc) return rc;
         return launch_tcq_gemm(mp, S, KV1, KV2, nbg_of(rows), grid, stream);
     }
+    if (nbg > 8) return QPAL_E_SHAPE;  // (batches 65..128: the lockstep kernel only — it needs 16-byte aligned x and k % 8 == 0)
     plan_launch(mp, nullptr, grid, waves_of(nbg));
     int rc = zero_if_split(mp.job[0], m, stream);
     if (rc) return rc;
@@ -774,6 +777,7 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
         if (rc) return rc;
         return launch_tcq_gemm(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, nbg_of(rows), grid, s);
     }
+    if (nbg > 8) return QPAL_E_SHAPE;  // (batches 65..128: the lockstep kernel only)
     plan_launch(mp, zeroed, grid, waves_of(nbg));
     for (int j = 0; j < njobs; j++) {
         ms[j] = jobs[j].m;
@@ -930,6 +934,7 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
         if (rc) return rc;
         return launch_lut_tc_gemm(mp, bits, vec, nbg_of(rows), grid, s);
     }
+    if (nbg > 8) return QPAL_E_SHAPE;  // (batches 65..128: the lockstep kernel only)
     plan_launch(mp, zeroed, grid, waves_of(nbg));
     for (int j = 0; j < njobs; j++) {
         ms[j] = jobs[j].m;

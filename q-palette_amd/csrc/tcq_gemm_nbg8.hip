@@ -1,3 +1,3 @@
-// TCQ fused decode + skinny GEMM with the step's activations shared through LDS (tc_gemm.h), 8 batch groups (batch <= 64).
+// TCQ fused decode + skinny GEMM, lane-pair-exchange mapping (tc_gemm16.h), 4 groups of 16 batch rows (batch <= 64).
 #define QPAL_GEMM_NBG 8
 #include "tcq_gemm_inst.inc"

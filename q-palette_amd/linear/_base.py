@@ -11,7 +11,7 @@ GEMV_MAX_BATCH = 8  # reference: `if bs <= 8` in every forward (e.g. lib/linear/
 class PackedLinearBase(nn.Module):
     in_features: int
     out_features: int
-    max_fused_batch = GEMV_MAX_BATCH  # tensor-core-order families raise this to 64 (8 MFMA column groups; 32 under a 128 KiB image)
+    max_fused_batch = GEMV_MAX_BATCH  # tensor-core-order families raise this to 128 (8 groups of 16 batch rows; 64 under a 128 KiB image)
     # up to this batch the forward runs ceil(bs / max_fused_batch) passes of the fused kernel instead of decode-to-HBM + GEMM:
     # measured on Llama-8B shapes the passes win up to ~2 x 64 rows; 0: no chunked passes (SIMT packings)
     max_chunked_batch = 0

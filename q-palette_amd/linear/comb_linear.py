@@ -13,8 +13,8 @@ def _trellis_buffer(rows, cols, KV, td_x=16, td_y=16, V=2):
 
 
 class _CombBase(PackedLinearBase):
-    max_fused_batch = 64  # batches 9..64: 2 / 4 / 8 MFMA column groups per decoded step (csrc/tc_gemm.h)
-    max_chunked_batch = 128
+    max_fused_batch = 128  # batches 9..128: 1 / 2 / 4 / 8 groups of 16 batch rows per decoded step (csrc/tc_gemm16.h)
+    max_chunked_batch = 256
     part_key = None
 
     def _common_init(self, in_features, out_features, td_x, td_y, part, L, KV, V, tlut_bits, bias, dtype):

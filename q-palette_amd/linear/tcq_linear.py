@@ -8,8 +8,8 @@ from ._base import PackedLinearBase, merge_row_concat, op
 
 
 class QTIPLinearTCQ(PackedLinearBase):
-    max_fused_batch = 64  # batches 9..64: 2 / 4 / 8 MFMA column groups per decoded step (csrc/tc_gemm.h)
-    max_chunked_batch = 128
+    max_fused_batch = 128  # batches 9..128: 1 / 2 / 4 / 8 groups of 16 batch rows per decoded step (csrc/tc_gemm16.h)
+    max_chunked_batch = 256
     def __init__(self, in_features, out_features, td_x, td_y, L, KV, V, tlut_bits, bias=False, dtype=torch.float16):
         super().__init__()
         assert td_x == 16 and td_y == 16 and L == 16 and V == 2, "kernel format is 16x16 tiles, L=16, V=2"

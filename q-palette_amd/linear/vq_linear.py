@@ -46,15 +46,15 @@ class VQLinearPackTensorCore(_VQBase):
     """Codes stored in mma-tile order (quant_op.py:101-162).  forward() returns the input's dtype.  `_gemv` (internal) returns fp32 from
     the tensor-core-order kernel and fp16 from the SIMT-order twin that few-row layers keep (fp32 accumulation in both; which of the
     two runs depends only on the layer's shape and QPAL_SIMT_TWIN, see _simt_twin)."""
-    max_fused_batch = 64
+    max_fused_batch = 128
 
     def __init__(self, in_features, out_features, lut_bits, vec_sz=2, bias=False, dtype=torch.half, device=None):
         super().__init__(in_features, out_features, lut_bits, vec_sz, bias, dtype, device)
         self.vq_type = f"vq{vec_sz}" if vec_sz > 1 else ("sq_dup" if lut_bits <= 4 else "sq")
-        # the reduction buffer of 8 batch groups does not fit beside a 128 KiB codebook image (csrc/qpal_capi.hip)
+        # beside a 128 KiB codebook image the LDS holds the x tiles of 64 batch rows, not of 128 (csrc/lut_gemm.hip)
         idx = lut_bits if vec_sz == 2 else (2 * lut_bits if lut_bits <= 6 else lut_bits)
         if (4 << (idx + min(15 - idx, 5))) > 64 * 1024:
-            self.max_fused_batch = 32
+            self.max_fused_batch = 64
         self.max_chunked_batch = 2 * self.max_fused_batch
         self.register_ops()
 

@@ -344,7 +344,7 @@ def tcq_gemv_multi(streams, x, S, KV1, KV2=0, split=0, outs=None, outs_zeroed=Fa
     wscales / oscale: fused epilogue out = acc * wscales[j][row] * oscale (the incoherent wrappers' Wscale * scale).
     x_rot = (su, post): x is the un-rotated input; the kernel stages fp16(fp16(H (x * su) / sqrt(k)) * post) itself."""
     n, k = x.shape
-    _chk(1 <= n <= MAX_FUSED_BATCH, "batch size must be in 1..64")
+    _chk(1 <= n <= MAX_FUSED_BATCH, "batch size must be in 1..128")
     xh, x32 = _x_arg(x, x_rot)
     had, xpost, xsu, xhadk, xK = _rot_args(x_rot, x, k)
     rms_eps, rms_w = _rms_args(x_rms, k)
@@ -394,7 +394,7 @@ def lut_tc_gemv_multi(layers, x, bits, vec, outs=None, outs_zeroed=False, prezer
     """Several VQ/SQ (tensor-core packing) GEMVs of one codec and one input in ONE launch.
     layers: list of (qweight, lut, m); x: [n, k].  outs / outs_zeroed / prezero as in tcq_gemv_multi."""
     n, k = x.shape
-    _chk(1 <= n <= MAX_FUSED_BATCH, "batch size must be in 1..64")
+    _chk(1 <= n <= MAX_FUSED_BATCH, "batch size must be in 1..128")
     xh, x32 = _x_arg(x, x_rot)
     had, xpost, xsu, xhadk, xK = _rot_args(x_rot, x, k)
     rms_eps, rms_w = _rms_args(x_rms, k)
@@ -462,7 +462,7 @@ def _tcq_ok(S, KV):
     return S in _TCQ_KV and KV in _TCQ_KV[S]
 
 
-MAX_FUSED_BATCH = 64  # the reference's fused ops stop at 8; here a decoded step feeds up to 8 MFMA column groups of 8 rows
+MAX_FUSED_BATCH = 128  # the reference's fused ops stop at 8; here a decoded step feeds up to 8 MFMA column groups of 16 batch rows
 
 
 def _shape_ok(m, n, k):

@@ -254,11 +254,11 @@ def test_mi355x_latency_table_is_loadable_by_the_reference_solver():
 
 @pytest.mark.parametrize("cls,part", [("CombLinearTCQ", (128, 128)), ("CombtLinearTCQ", (64, 192))])
 def test_batches_above_the_fused_batch_do_not_recurse_on_layers_without_a_multi_job_form(cls, part, monkeypatch):
-    """Row-split (comb_*) layers and column-split ones with unequal parts run no multi-job launch; for 64 < bs <= 128 their forward
+    """Row-split (comb_*) layers and column-split ones with unequal parts run no multi-job launch; for 128 < bs <= 256 their forward
     goes through multi_gemv's chunked branch, which must run passes of the layer's OWN fused launch (it used to call the
     forward again: RecursionError).  Host dispatch only: _gemv is replaced by a recorder, no kernel runs."""
     layer = getattr(qp, cls)(256, 256, 16, 16, part, 16, (3, 4), 2, 9)
-    assert qp.linear._codec_key(layer)[0] == "single" and layer.max_chunked_batch == 128
+    assert qp.linear._codec_key(layer)[0] == "single" and layer.max_chunked_batch == 256
     calls = []
 
     def fake_gemv(self, x, bs):
@@ -267,7 +267,7 @@ def test_batches_above_the_fused_batch_do_not_recurse_on_layers_without_a_multi_
         return torch.full((bs, self.out_features), float(len(calls)))
 
     monkeypatch.setattr(type(layer), "_gemv", fake_gemv)
-    for bs, want in ((65, [64, 1]), (100, [64, 36]), (128, [64, 64])):
+    for bs, want in ((129, [128, 1]), (200, [128, 72]), (256, [128, 128])):
         calls.clear()
         y = layer(torch.zeros(bs, 256).half())
         assert calls == want and tuple(y.shape) == (bs, 256) and y.dtype == torch.float16

@@ -510,17 +510,19 @@ def test_llama70b_shapes(qp, oracle, qstr, k, m):
                                       ("ldlq_1_4_none_1.0", 4096, 2048), ("ldlq_2_12_none_1.0", 4096, 1024),
                                       ("tcq_6_none_0.9", 14336, 4096), ("tcq_6_none_0.9", 8192, 1024),
                                       ("tcomb_6_7_0.5_none_0.9", 8192, 8192), ("ldlq_2_8_none_1.0", 4096, 1024)])
-def test_fused_skinny_gemm_batch_9_to_64(qp, oracle, qstr, k, m):
-    """Batches 9..64 run in the fused kernel too: one decoded step feeds 2 (16 waves per workgroup), 4 or 8 (8 waves) MFMA
-    column groups, x read from L2 — SURVEY N1 / north_star "batched dequant-then-GEMM tensor path", Llama-8B and 70B shapes.
-    Beyond the module's max_fused_batch (64; 32 where a 128 KiB codebook image leaves no room for 8 groups' reduction buffer)
-    the module decodes to fp16 and calls the fp16 GEMM, as the reference does for bs > 8 (lib/linear/tcq_linear.py:75-84)."""
+def test_fused_skinny_gemm_batch_9_to_128(qp, oracle, qstr, k, m):
+    """Batches 9..128 run in ONE fused launch: a decoded step feeds 1 / 2 / 4 / 8 groups of 16 batch rows, the MFMA's 16 rows being 16
+    real rows of W after the lane-pair exchange (csrc/tc_gemm16.h, round 5; rounds 2-4: 64 at most, 65..128 as two passes) — SURVEY N1 /
+    north_star "batched dequant-then-GEMM tensor path", Llama-8B and 70B shapes.  Beyond the module's max_fused_batch (128; 64 where a
+    128 KiB codebook image leaves the LDS no room for more x tiles) the module decodes to fp16 and calls the fp16 GEMM, as the reference
+    does for bs > 8 (lib/linear/tcq_linear.py:75-84)."""
     info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=5)
     layer = qp.make_linear_from_info(qstr, info).cuda()
-    assert layer.max_fused_batch == (32 if qstr.startswith("ldlq_2_12") else 64)
+    assert layer.max_fused_batch == (64 if qstr.startswith("ldlq_2_12") else 128)
     W = _oracle_weight(oracle, qstr, info, m, k)
     gen = torch.Generator().manual_seed(9)
-    for n in (9, 13, 16, 17, 31, 32, 33, 37, 50, 64):  # (from 32 on a few-row launch runs as two slices of the batch: 37 = 24 + 13)
+    # (from 32 on a few-row launch runs as two slices of the batch; 65 / 100 / 128: one pass where rounds 2-4 needed two)
+    for n in (9, 13, 16, 17, 31, 32, 33, 37, 50, 64, 65, 100, 128):
         if n > layer.max_fused_batch:
             continue
         x = torch.randn(n, k, generator=gen).half()
@@ -538,7 +540,7 @@ def test_batch_slices_of_a_multi_job_launch(qp, oracle):
     qp.share_codebooks(mods)
     Ws = [_oracle_weight(oracle, qstr, info, m, k) for info, m in zip(infos, (1024, 256, 256))]
     gen = torch.Generator().manual_seed(12)
-    for n in (32, 40, 64):
+    for n in (32, 40, 64, 96, 128):
         x = torch.randn(n, k, generator=gen).half()
         ys = qp.multi_gemv(mods, x.cuda())
         for y, W, m in zip(ys, Ws, (1024, 256, 256)):
@@ -770,13 +772,13 @@ def test_comb_layer_row_shards(qp, oracle):
         assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max())), world
 
 
-@pytest.mark.parametrize("qstr,k,m,n", [("tcomb_6_7_0.5_none_0.9", 4096, 4096, 128), ("tcq_6_none_0.9", 14336, 4096, 100),
-                                        ("ldlq_2_12_none_1.0", 4096, 1024, 48), ("ldlq_1_4_none_1.0", 4096, 2048, 65),
-                                        ("tcomb_6_7_0.5_none_0.9", 4096, 4096, 129), ("tcq_6_none_0.9", 14336, 4096, 200),
-                                        ("ldlq_2_12_none_1.0", 4096, 1024, 80), ("ldlq_1_4_none_1.0", 4096, 2048, 256),
+@pytest.mark.parametrize("qstr,k,m,n", [("tcomb_6_7_0.5_none_0.9", 4096, 4096, 256), ("tcq_6_none_0.9", 14336, 4096, 200),
+                                        ("ldlq_2_12_none_1.0", 4096, 1024, 96), ("ldlq_1_4_none_1.0", 4096, 2048, 130),
+                                        ("tcomb_6_7_0.5_none_0.9", 4096, 4096, 257), ("tcq_6_none_0.9", 14336, 4096, 300),
+                                        ("ldlq_2_12_none_1.0", 4096, 1024, 129), ("ldlq_1_4_none_1.0", 4096, 2048, 512),
                                         ("tcomb_6_7_0.5_none_0.9", 4096, 14336, 1024)])
 def test_module_path_above_the_fused_batch(qp, oracle, qstr, k, m, n):
-    """Above max_fused_batch the module runs passes of the fused kernel up to max_chunked_batch (2 x 64 rows) and beyond that the
+    """Above max_fused_batch the module runs passes of the fused kernel up to max_chunked_batch (2 x 128 rows) and beyond that the
     path the perplexity eval takes (bs = 8192 there: eval_qdict.py:17-38): W decoded to fp16 (bit-exact, checked elsewhere)
     times the fp16 GEMM, as the reference does for bs > 8 (lib/linear/tcq_linear.py:75-84).  Both against the oracle's fp64 GEMM
     on the oracle's W: fp32 accumulation + ONE fp16 rounding of the output."""
