@@ -14,7 +14,7 @@
  *   TCQ codebook  fp16   [2^S][2]                   lib/linear/tcq_linear.py:37-40
  *   LUT-TC        int32  [m][bits*k/32/vec], fp16 lut [2^bits][vec]   lib/linear/vq_linear.py:15-23
  *   LUT-SIMT      uint32 [m][bits*k/32/vec]         lib/quantizer/pack_op.py:288-335, quant_op.py:69-78
- *   x             fp16   [n][k] row-major, 1 <= n <= 64 (tensor-core-order families), 1 <= n <= 8 (SIMT)
+ *   x             fp16   [n][k] row-major, 1 <= n <= 128 (tensor-core-order families), 1 <= n <= 8 (SIMT)
  */
 #ifndef QPAL_H
 #define QPAL_H
@@ -28,7 +28,7 @@ extern "C" {
 #define QPAL_VERSION 300
 
 #define QPAL_OK 0
-#define QPAL_E_SHAPE (-1)   /* m, k, n outside the supported set (m%32, k%32, 1<=n<=64 ...) */
+#define QPAL_E_SHAPE (-1)   /* m, k, n outside the supported set (m%32, k%32, 1<=n<=128 ...) */
 #define QPAL_E_PARAM (-2)   /* S / KV / bits / vec / split combination not supported        */
 #define QPAL_E_NULL (-3)    /* required pointer is NULL                                      */
 #define QPAL_E_ALIGN (-4)   /* pointer not aligned to the format's natural alignment         */

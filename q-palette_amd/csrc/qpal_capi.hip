@@ -7,7 +7,7 @@
 
 #include "lut_kernels_api.h"
 #include "tcq_kernels_api.h"
-#include "tc_gemm.h"
+#include "tc_gemm16.h"
 #include <string.h>
 
 using namespace qpal;
@@ -18,7 +18,7 @@ constexpr int kMaxBatch = 128;  // fused decode + skinny GEMM: up to 8 groups of
 
 // batch -> 8-row units the kernels are instantiated for: 1, 2 (16 waves per workgroup), 4, 8 (8 waves: tc_kernels.h gemv_waves);
 // 16 (batch 65..128): the lockstep kernel of tc_gemm16.h only
-int nbg_of(int n) { return n <= 8 ? 1 : n <= 16 ? 2 : n <= 32 ? 4 : n <= 64 ? 8 : 16; }
+int nbg_of(int n) { return n <= 8 ? 1 : n <= 16 ? 2 : n <= 32 ? 4 : n <= 64 ? 8 : n <= 80 ? 10 : 16; }
 int waves_of(int nbg) { return gemv_waves<1>() == 8 ? 8 : (nbg >= 4 ? 8 : 16); }
 // workgroups one launch round can hold: one per CU; two with the 8-wave experiment build (tc_kernels.h QPAL_W8), whose
 // batch <= 16 kernels leave room for a second workgroup's LDS and registers
@@ -440,7 +440,7 @@ bool gemv_classes_ok(const TcMultiParams &mp) {
 constexpr int kGemmMinSteps = 4;
 // two_per_cu: one batch group beside a 64 KiB codebook image (75 KiB of LDS, < 128 VGPRs): two workgroups share a CU — 4 waves per
 // SIMD hide each other's barrier waits — and the launch is planned for twice the items (batch 4 / 8: +3 % tokens/s, measured).
-void plan_gemm(TcMultiParams &mp, int &grid, bool two_per_cu = false) {
+void plan_gemm(TcMultiParams &mp, int &grid, bool two_per_cu = false, int wg_rows = kGemmWaves) {
     static const int force_sk = env_int("QPAL_GEMM_SK", 0);
     static const int items_env = env_int("QPAL_GEMM_ITEMS", 0);  // measured: 96 / 192 / 256 / 512 -> 4.9 / 4.1 / 4.5 / 5.3 ms per Llama-8B step at batch 64
     static const int mult_env = env_int("QPAL_GEMM_GRID_MULT", 0);
@@ -448,7 +448,7 @@ void plan_gemm(TcMultiParams &mp, int &grid, bool two_per_cu = false) {
     const int want_items = items_env > 0 ? items_env : 192 * grid_mult;
     static const int min_steps = env_int("QPAL_GEMM_MINSTEPS", kGemmMinSteps);
     int groups = 0;
-    for (int j = 0; j < mp.njobs; j++) groups += (mp.job[j].nrows + kGemmWaves - 1) / kGemmWaves;
+    for (int j = 0; j < mp.njobs; j++) groups += (mp.job[j].nrows + wg_rows - 1) / wg_rows;
     int total = 0;
     for (int j = 0; j < kMaxJobs; j++) {
         if (j < mp.njobs) {
@@ -462,7 +462,7 @@ void plan_gemm(TcMultiParams &mp, int &grid, bool two_per_cu = false) {
             }
             while (sk > 1 && sk > T) sk >>= 1;
             p.sk = sk;
-            p.nitems = ((p.nrows + kGemmWaves - 1) / kGemmWaves) * sk;
+            p.nitems = ((p.nrows + wg_rows - 1) / wg_rows) * sk;
             total += p.nitems;
         }
         mp.item_end[j] = total;
@@ -586,6 +586,7 @@ int launch_tcq_gemm(const TcMultiParams &mp, int S, int KV1, int KV2, int nbg, i
          : nbg == 2 ? launch_tcq_gemm_nbg2(mp, S, KV1, KV2, grid, stream)
          : nbg == 4 ? launch_tcq_gemm_nbg4(mp, S, KV1, KV2, grid, stream)
          : nbg == 8 ? launch_tcq_gemm_nbg8(mp, S, KV1, KV2, grid, stream)
+         : nbg == 10 ? launch_tcq_gemm_nbg10(mp, S, KV1, KV2, grid, stream)
                     : launch_tcq_gemm_nbg16(mp, S, KV1, KV2, grid, stream);
 }
 
@@ -630,7 +631,7 @@ int tcq_gemv_one(float *out, long ldo, const void *c1, const void *c2, const voi
     if (use_gemm(nbg, mp)) {
         int ms[kMaxJobs] = {m}, zeroed[kMaxJobs] = {0};
         const int rows = slice_gemm_batch(mp, ms, zeroed);
-        plan_gemm(mp, grid, nbg_of(rows) == 1 && S == 9);
+        plan_gemm(mp, grid, nbg_of(rows) <= env_int("QPAL_GEMM_TWO_NBG", 1) && S == 9, nbg_of(rows) >= 4 ? kG16Waves : kGemmWaves);
         int rc = zero_split_jobs(mp, ms, zeroed, stream);
         if (rc) return rc;
         return launch_tcq_gemm(mp, S, KV1, KV2, nbg_of(rows), grid, stream);
@@ -772,7 +773,7 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
             zeroed[j] = jobs[j].out_zeroed;
         }
         const int rows = slice_gemm_batch(mp, ms, zeroed);
-        plan_gemm(mp, grid, nbg_of(rows) == 1 && S == 9);
+        plan_gemm(mp, grid, nbg_of(rows) <= env_int("QPAL_GEMM_TWO_NBG", 1) && S == 9, nbg_of(rows) >= 4 ? kG16Waves : kGemmWaves);
         int rc = zero_split_jobs(mp, ms, zeroed, s);
         if (rc) return rc;
         return launch_tcq_gemm(mp, S, KV1, split == QPAL_SPLIT_NONE ? 0 : KV2, nbg_of(rows), grid, s);
@@ -920,7 +921,7 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
     int grid;
     const int nbg = nbg_of(n);
     // the reduction buffer of 8 batch groups (64 KiB) does not fit beside a 128 KiB codebook image
-    if (nbg == 8 && lut_image_bytes(bits, vec) > 64 * 1024) return QPAL_E_SHAPE;
+    if (nbg >= 10 && lut_image_bytes(bits, vec) > 64 * 1024) return QPAL_E_SHAPE;  // (128 KiB image: the LDS holds the x tiles of 64 batch rows)
     const bool gemm = use_gemm(nbg, mp);
     int ms[kMaxJobs] = {0};
     if (gemm) {
@@ -929,7 +930,7 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
             zeroed[j] = jobs[j].out_zeroed;
         }
         const int rows = slice_gemm_batch(mp, ms, zeroed);
-        plan_gemm(mp, grid, nbg_of(rows) == 1 && lut_image_bytes(bits, vec) <= 64 * 1024);
+        plan_gemm(mp, grid, nbg_of(rows) <= env_int("QPAL_GEMM_TWO_NBG", 1) && lut_image_bytes(bits, vec) <= 64 * 1024, nbg_of(rows) >= 4 ? kG16Waves : kGemmWaves);
         int rc = zero_split_jobs(mp, ms, zeroed, s);
         if (rc) return rc;
         return launch_lut_tc_gemm(mp, bits, vec, nbg_of(rows), grid, s);
@@ -1072,7 +1073,7 @@ int qpal_can_fuse_rotation_k(int n, int k, int K) {
 const char *qpal_error_string(int code) {
     switch (code) {
         case QPAL_OK: return "ok";
-        case QPAL_E_SHAPE: return "unsupported shape (need m%32==0, k%32==0, 1<=n<=64; see include/qpal.h)";
+        case QPAL_E_SHAPE: return "unsupported shape (need m%32==0, k%32==0, 1<=n<=128; see include/qpal.h)";
         case QPAL_E_PARAM: return "unsupported quantizer parameters (S/KV/bits/vec/split)";
         case QPAL_E_NULL: return "null pointer";
         case QPAL_E_ALIGN: return "misaligned pointer";

@@ -170,6 +170,8 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const int eie,
     constexpr int NWMAX = C1::NW > CB::NW ? C1::NW : CB::NW;
     // Tile slots: 4 where they fit beside the codebook image (two steps per buffer: the workgroup barrier — 9 % of a batch-64 token
     // as a per-step barrier, knock-out 8 — falls after every SECOND step, tiles are staged two steps ahead), else 2 (one per step)
+    // (round 5, measured and not kept: two batch groups on TWO slots — 73 KiB of LDS, < 128 VGPRs — so that two workgroups share a CU as at
+    // one batch group: +-0 on Llama-8B at batch 12 / 16, -7 % on the 70B shapes at batch 16; profiles/r05_ab_batched_path.txt)
     constexpr int NSLOT = (QPAL_GEMM_SLOTS == 4 && C1::LDS_DWORDS * 4 + 4 * XBUF <= 156 * 1024) ? 4 : 2;
     constexpr int AHEAD = NSLOT / 2;
     constexpr int XT = NSLOT * XBUF >= W * 1024 ? NSLOT * XBUF : W * 1024;  // the x buffers double as the epilogue's per-wave transposition scratch

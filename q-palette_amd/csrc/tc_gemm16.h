@@ -23,6 +23,11 @@
 
 namespace qpal {
 
+// waves = supertile rows per workgroup of this kernel (experiments: -DQPAL_G16_WAVES=16 -DQPAL_G16_PIPE=0 — 16 waves need <= 128 VGPRs)
+#ifndef QPAL_G16_WAVES
+#define QPAL_G16_WAVES 8
+#endif
+constexpr int kG16Waves = QPAL_G16_WAVES;
 constexpr int kG16Group = 4096;  // bytes of one step's x tile per 16 batch rows: [sup 4][ksub, jh 4][slot 16][16 B]
 
 // x tile layout.  The 16-byte piece (batch row b, columns 8 q .. 8 q + 7 of the step; q = 4 sup + 2 ksub + jh) lives at
@@ -32,20 +37,24 @@ constexpr int kG16Group = 4096;  // bytes of one step's x tile per 16 batch rows
 // banks as well (without it they all hit one 16-byte window: 8-way conflicts on every staging store).
 __device__ __forceinline__ int g16_x_off(int b, int q) { return (b >> 4) * kG16Group + q * 256 + (((b + q) & 15) << 4); }
 
-// A fragment of tile group G = ksub * 2 + msub, column block JH: the exchange.  Pair index I = jl + 2 jh + 4 isB (tc_kernels.h
-// gemv_step); a lane's pairs (jl, jh) are columns 4 u + 0..3 (isB = 0: +0, 1; isB = 1: +2, 3) of tile row (p >> 1) + 8 jl.
+// The four decoded pairs an A fragment is made of — tile group G = ksub * 2 + msub, column block JH.  Pair index I = jl + 2 jh + 4 isB
+// (tc_kernels.h gemv_step); a lane's pairs (jl, jh) are columns 4 u + 0..3 (isB = 0: +0, 1; isB = 1: +2, 3) of tile row (p >> 1) + 8 jl.
+struct G16Pairs {
+    uint32_t p0a, p0b, p1a, p1b;  // p0: tile row r (jl = 0), p1: tile row r + 8 (jl = 1)
+};
 template <class Codec, int G, int JH>
-__device__ __forceinline__ u32x4 g16_afrag(const uint32_t *lut, uint32_t laneoff, const uint32_t (&w)[Codec::NW]) {
+__device__ __forceinline__ G16Pairs g16_pairs(const uint32_t *lut, uint32_t laneoff, const uint32_t (&w)[Codec::NW]) {
     uint32_t nh = 0u;
     if constexpr (Codec::kNeedsNext) nh = row16_next(Codec::template head<G>(w));  // (one per G: CSE)
-    // own pairs: p0 = tile row r (jl = 0), p1 = tile row r + 8 (jl = 1)
-    const uint32_t p0a = Codec::template pair<G, 0 + 2 * JH>(lut, laneoff, w, nh), p0b = Codec::template pair<G, 0 + 2 * JH + 4>(lut, laneoff, w, nh);
-    const uint32_t p1a = Codec::template pair<G, 1 + 2 * JH>(lut, laneoff, w, nh), p1b = Codec::template pair<G, 1 + 2 * JH + 4>(lut, laneoff, w, nh);
-    // even lane (u = 0): row r, columns 0..3 own (p0), 4..7 the partner's p0; odd lane: row r + 8, columns 0..3 the partner's p1, 4..7
-    // own (p1).  "The partner's" = lane ^ 1 = DPP quad_perm [1, 0, 3, 2], folded into the select: v_cndmask_b32_dpp computes
-    // vcc ? src1 : dpp(src0) — ONE full-rate instruction per pair.  (Written as a move + a select the compiler emitted both: 64 more
-    // vector instructions per step, 233 instead of ~170.)  Hazards the assembler does not see inside an asm: a DPP operand written
-    // by the VALU instruction right in front needs two wait states (s_nop 1); SALU writes of VCC are interlocked.
+    return G16Pairs{Codec::template pair<G, 0 + 2 * JH>(lut, laneoff, w, nh), Codec::template pair<G, 0 + 2 * JH + 4>(lut, laneoff, w, nh),
+                    Codec::template pair<G, 1 + 2 * JH>(lut, laneoff, w, nh), Codec::template pair<G, 1 + 2 * JH + 4>(lut, laneoff, w, nh)};
+}
+// The exchange.  Even lane (u = 0): row r, columns 0..3 own (p0), 4..7 the partner's p0; odd lane: row r + 8, columns 0..3 the
+// partner's p1, 4..7 own (p1).  "The partner's" = lane ^ 1 = DPP quad_perm [1, 0, 3, 2], folded into the select: v_cndmask_b32_dpp
+// computes vcc ? src1 : dpp(src0) — ONE full-rate instruction per pair.  (Written as a move + a select the compiler emitted both: 64
+// more vector instructions per step.)  Hazards the assembler does not see inside an asm: a DPP operand written by the VALU
+// instruction right in front needs two wait states (s_nop 1); SALU writes of VCC are interlocked.
+__device__ __forceinline__ u32x4 g16_xchg(const G16Pairs &q) {
     uint32_t x, y, z, w_;
     asm("s_nop 1\n\t"
         "s_mov_b64 vcc, %[even]\n\t"
@@ -55,38 +64,70 @@ __device__ __forceinline__ u32x4 g16_afrag(const uint32_t *lut, uint32_t laneoff
         "v_cndmask_b32_dpp %[z], %[p0a], %[p1a], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "v_cndmask_b32_dpp %[w], %[p0b], %[p1b], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
         : [x] "=&v"(x), [y] "=&v"(y), [z] "=&v"(z), [w] "=&v"(w_)
-        : [p0a] "v"(p0a), [p0b] "v"(p0b), [p1a] "v"(p1a), [p1b] "v"(p1b), [even] "s"(0x5555555555555555ull)
+        : [p0a] "v"(q.p0a), [p0b] "v"(q.p0b), [p1a] "v"(q.p1a), [p1b] "v"(q.p1b), [even] "s"(0x5555555555555555ull)
         : "vcc", "scc");
     return u32x4{x, y, z, w_};
 }
 
-// One step: per (ksub, jh) the B fragments of the NG batch groups (8 consecutive columns of batch row 16 grp + c), then per msub one
-// A fragment and NG MFMAs.  acc[grp][msub] accumulates the 16 rows 16 msub + (r, r + 8) x 16 batch rows.
+// One step: 8 A fragments t = 2 kj + msub (kj = 2 ksub + jh), each feeding NG MFMAs — acc[grp][msub] accumulates the 16 rows
+// 16 msub + (r, r + 8) x 16 batch rows; per kj the B fragments of the NG batch groups (8 consecutive columns of batch row 16 grp + c).
+// Software-pipelined (QPAL_G16_PIPE, default): a wave issues in order, and left to the compiler a fragment is decode -> wait for the
+// gathers -> exchange -> NG MFMAs; here the pairs of fragment t + 1 are decoded and gathered in front of the MFMAs of fragment t and
+// exchanged behind them (the MFMAs cover the gather latency), and the B fragments of kj + 1 are read behind the last use of kj's.
+#ifndef QPAL_G16_PIPE
+#define QPAL_G16_PIPE 1
+#endif
+template <class Codec, int T>
+__device__ __forceinline__ G16Pairs g16_pairs_t(const uint32_t *lut, uint32_t laneoff, const uint32_t (&w)[Codec::NW]) {
+    constexpr int kj = T >> 1, msub = T & 1, ksub = kj >> 1, jh = kj & 1;
+    return g16_pairs<Codec, ksub * 2 + msub, jh>(lut, laneoff, w);
+}
 template <class Codec, int NG>
 __device__ __forceinline__ void g16_step(const uint32_t *lut, uint32_t laneoff, const uint32_t (&w)[Codec::NW], const unsigned char *xt, int lane,
                                          float4_t (&acc)[NG][2]) {
     const int sup = lane >> 4, c = lane & 15;
-    static_for<0, 4>([&](auto kjc) {
-        constexpr int kj = decltype(kjc)::value, ksub = kj >> 1, jh = kj & 1;
-        const int off = (4 * sup + kj) * 256 + (((c + 4 * sup + kj) & 15) << 4);
-        u32x4 xb[NG];
-        static_for<0, NG>([&](auto gc) { xb[decltype(gc)::value] = *reinterpret_cast<const u32x4 *>(xt + decltype(gc)::value * kG16Group + off); });
-        static_for<0, 2>([&](auto mc) {
-            constexpr int msub = decltype(mc)::value;
-            const u32x4 a = g16_afrag<Codec, ksub * 2 + msub, jh>(lut, laneoff, w);
+    auto xoff = [&](int kj) { return (4 * sup + kj) * 256 + (((c + 4 * sup + kj) & 15) << 4); };
+    if constexpr (QPAL_G16_PIPE != 0) {
+        u32x4 xb[NG], xn[NG];
+        static_for<0, NG>([&](auto gc) { xb[decltype(gc)::value] = *reinterpret_cast<const u32x4 *>(xt + decltype(gc)::value * kG16Group + xoff(0)); });
+        u32x4 a = g16_xchg(g16_pairs_t<Codec, 0>(lut, laneoff, w));
+        static_for<0, 8>([&](auto tc) {
+            constexpr int t = decltype(tc)::value, kj = t >> 1, msub = t & 1;
+            G16Pairs nx{};
+            if constexpr (t < 7) nx = g16_pairs_t<Codec, t + 1>(lut, laneoff, w);
+            if constexpr (msub == 1 && kj < 3)  // the next column block's B fragments, in flight behind this fragment's MFMAs
+                static_for<0, NG>([&](auto gc) { xn[decltype(gc)::value] = *reinterpret_cast<const u32x4 *>(xt + decltype(gc)::value * kG16Group + xoff(kj + 1)); });
+            __builtin_amdgcn_sched_barrier(0);
             static_for<0, NG>([&](auto gc) {
                 constexpr int grp = decltype(gc)::value;
                 acc[grp][msub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, xb[grp]), acc[grp][msub], 0, 0, 0);
             });
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (t < 7) a = g16_xchg(nx);
+            if constexpr (msub == 1 && kj < 3) static_for<0, NG>([&](auto gc) { xb[decltype(gc)::value] = xn[decltype(gc)::value]; });
         });
-    });
+    } else {
+        static_for<0, 4>([&](auto kjc) {
+            constexpr int kj = decltype(kjc)::value, ksub = kj >> 1, jh = kj & 1;
+            u32x4 xb[NG];
+            static_for<0, NG>([&](auto gc) { xb[decltype(gc)::value] = *reinterpret_cast<const u32x4 *>(xt + decltype(gc)::value * kG16Group + xoff(kj)); });
+            static_for<0, 2>([&](auto mc) {
+                constexpr int msub = decltype(mc)::value;
+                const u32x4 a = g16_xchg(g16_pairs<Codec, ksub * 2 + msub, jh>(lut, laneoff, w));
+                static_for<0, NG>([&](auto gc) {
+                    constexpr int grp = decltype(gc)::value;
+                    acc[grp][msub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, xb[grp]), acc[grp][msub], 0, 0, 0);
+                });
+            });
+        });
+    }
 }
 
 template <class C1, class C2, int NG>
-__global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm16_kernel(const int eie, const TcMultiParams mp) {
+__global__ __launch_bounds__(64 * kG16Waves) void tc_gemm16_kernel(const int eie, const TcMultiParams mp) {
     constexpr bool TWO = !std::is_void_v<C2>;
     using CB = std::conditional_t<TWO, C2, C1>;
-    constexpr int W = kGemmWaves, NT = 64 * W;
+    constexpr int W = kG16Waves, NT = 64 * W;
     constexpr int XBUF = NG * kG16Group;
     constexpr int NCH = NG * 16 * 16;                   // 16-byte chunks of one step's x tile
     constexpr int CPT = (NCH + NT - 1) / NT;            // chunks per thread

@@ -177,7 +177,7 @@ def multi_gemv(layers, x, outs=None, outs_zeroed=False, prezero=None, wscales=No
     fused = min(l.max_fused_batch for l in layers)
     if n > fused:
         if outs is not None or prezero is not None or wscales is not None or oscale != 1.0 or x_rot is not None or accumulate:
-            raise RuntimeError("multi_gemv: outs / prezero / wscales / oscale / x_rot need a fused batch (n <= 64)")
+            raise RuntimeError("multi_gemv: outs / prezero / wscales / oscale / x_rot need a fused batch (n <= 128)")
         if n <= min(l.max_chunked_batch for l in layers):
             # passes of the fused launches over slices of the batch (each pass keeps the multi-job grouping): faster than
             # decode-to-HBM + GEMM up to ~2 passes

@@ -16,7 +16,7 @@ Name grammar (reference file:line):
   decompress_{bits}_{vtype}                                     :94-117
   sq_pack_gemm_simt / sq_pack_dequant_simt / sq_pack_gemm_inplace_simt   :349-378
   vq_pack_gemm_simt_{maxm}_{vec}_{bits} ; vq_pack_dequant_simt_{vec}_{bits}   :383-420
-Unlike the reference, any 1 <= n <= 64 (tensor-core-order families; SIMT: n <= 8) and any m % 32 == 0,
+Unlike the reference, any 1 <= n <= 128 (tensor-core-order families; SIMT: n <= 8) and any m % 32 == 0,
 k % 32 == 0 is accepted at run time.
 """
 import re

@@ -41,7 +41,7 @@ def test_argument_errors_are_return_codes_not_exits():
     buf = np.zeros(1 << 16, dtype=np.uint8)
     p = buf.ctypes.data
     assert lib.qpal_tcq_gemv(p, p, None, p, p, 4100, 1, 4096, 9, 6, 0, 0, None) == -1   # m % 32
-    assert lib.qpal_tcq_gemv(p, p, None, p, p, 4096, 65, 4096, 9, 6, 0, 0, None) == -1  # n > 64
+    assert lib.qpal_tcq_gemv(p, p, None, p, p, 4096, 129, 4096, 9, 6, 0, 0, None) == -1  # n > 128
     assert lib.qpal_tcq_gemv(p, p, None, p, p, 4096, 1, 4096, 9, 11, 0, 0, None) == -2  # KV outside the table
     assert lib.qpal_tcq_gemv(p, p, p, p, p, 4096, 1, 4096, 9, 6, 8, 2, None) == -2      # KV2 != KV1 + 1
     assert lib.qpal_lut_tc_gemv(p, p, p, p, 4096, 1, 4096, 9, 1, None) == -2            # sq has bits <= 8
@@ -50,13 +50,13 @@ def test_argument_errors_are_return_codes_not_exits():
 
 def test_op_name_grammar():
     good = ["decompress_gemm_tcq_4096_1_4096_9_6", "decompress_gemm_tcq_1024_7_4096_9_10", "decompress_gemm_tcq_1024_16_4096_9_6",
-            "decompress_gemm_tcq_1024_64_4096_9_6",
+            "decompress_gemm_tcq_1024_64_4096_9_6", "decompress_gemm_tcq_1024_128_4096_9_6",
             "decompress_gemm_tcq_combt_14336_1_4096_9_6_7", "decompress_gemm_tcq_comb_4096_8_4096_10_9_10",
             "decompress_tcq_9_2", "decompress_tcq_combt_11_9_10", "decompress_gemm_4096_2_4096_4_sq_dup",
             "decompress_gemm_4096_1_4096_8_sq", "decompress_gemm_28672_1_4096_12_vq2", "decompress_gemv_4096_4096_4_sq",
             "decompress_6_sq", "vq_pack_gemm_simt_4_2_8", "vq_pack_dequant_simt_4_12", "sq_pack_gemm_simt"]
     bad = ["decompress_gemm_tcq_4096_1_4096_9_11", "decompress_gemm_tcq_4096_1_4096_10_7", "decompress_tcq_12_9",
-           "decompress_gemm_tcq_4100_1_4096_9_6", "decompress_gemm_tcq_4096_65_4096_9_6",
+           "decompress_gemm_tcq_4100_1_4096_9_6", "decompress_gemm_tcq_4096_129_4096_9_6",
            "decompress_gemm_tcq_combt_4096_1_4096_9_6_8", "decompress_gemm_4096_1_4096_5_sq_dup",
            "decompress_gemm_4096_1_4096_13_vq2", "vq_pack_gemm_simt_1_4_5", "vq_pack_gemm_simt_1_3_8", "nonsense"]
     for name in good:

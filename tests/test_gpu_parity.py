@@ -271,10 +271,10 @@ def test_llama_shapes_modules(qp, oracle, qstr, k, m):
         simt_twin = isinstance(layer, qp.VQLinearPackTensorCore) and m <= layer.SIMT_TWIN_MAX_ROWS
         assert simt_twin == (getattr(layer, "_simt_qweight", None) is not None)
         _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle, fp16_out=simt_twin)
-    # bs > max_fused_batch (64): the module's decode-to-fp16 + fp16 GEMM path — what the perplexity eval exercises
+    # bs > max_chunked_batch (2 x max_fused_batch = 256; SIMT packings: 8): the module's decode-to-fp16 + fp16 GEMM path — what the perplexity eval exercises
     # (eval_qdict.py:17-38 at bs = 8192; lib/linear/tcq_linear.py:75-84); tighter check: test_module_path_above_the_fused_batch
-    x = torch.randn(80, k, generator=gen).half()
-    assert x.shape[0] > layer.max_fused_batch
+    x = torch.randn(272, k, generator=gen).half()
+    assert x.shape[0] > max(layer.max_fused_batch, layer.max_chunked_batch)
     y = layer(x.cuda()).float().cpu().numpy()
     ref = (x.float() @ torch.from_numpy(W).float().T).numpy()
     assert np.allclose(y, ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max())
