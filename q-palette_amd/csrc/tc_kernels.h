@@ -167,8 +167,10 @@ struct TcqCodec {
     // e << (15-S), i.e. exactly where those bits already sit in h, replicated over the 2^(15-S) bytes of
     // its row (16 / 8 / 4 dword copies for S = 9 / 10 / 11; 64 KiB for every S).  The gather address is
     // then ONE v_and_or_b32: (h & mask) | 4*(lane mod copies).  Lanes l and l+16 of a 32-lane ds_read_b32
-    // group share a copy, so half of the gathers are 2-way bank conflicts: LDS has the slack, the
-    // half-rate VALU does not (perf/valu_rate.hip).
+    // group share a copy, so half of the gathers are 2-way bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.42).  Neither
+    // pipe has slack any more: with the pipelined step the VALU and the LDS are each ~73 % busy (545 VALU and 525 LDS
+    // cycles of the ~740 a wave-step takes) — the conflict-free 32-copy image (XS = 1) trades a fourth VALU op per pair for them and
+    // measured -12 % when the VALU was the scarcer pipe (round 3); not re-measured since.
     static constexpr int XS = XS_;
     static constexpr int ROWSHIFT = 15 - S + XS;       // log2(bytes per entry row)
     static constexpr int LOG2C = ROWSHIFT - 2;         // copies per entry
