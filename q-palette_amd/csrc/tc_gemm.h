@@ -17,7 +17,10 @@
 
 namespace qpal {
 
-constexpr int kGemmWaves = 8;
+#ifndef QPAL_GEMM_WAVES  // (experiment: -DQPAL_GEMM_WAVES=16 — four waves per SIMD, <= 128 VGPRs)
+#define QPAL_GEMM_WAVES 8
+#endif
+constexpr int kGemmWaves = QPAL_GEMM_WAVES;
 constexpr int kGemmXRow = 144;              // bytes per (batch row, column half) row of a step's x tile: 128 + 16 pad (bank spread)
 constexpr int kGemmXGroup = 16 * kGemmXRow;  // one batch group (8 rows x 2 column halves)
 
@@ -175,8 +178,11 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const int eie,
     constexpr int NSLOT = (QPAL_GEMM_SLOTS == 4 && C1::LDS_DWORDS * 4 + 4 * XBUF <= 156 * 1024) ? 4 : 2;
     constexpr int AHEAD = NSLOT / 2;
     constexpr int XT = NSLOT * XBUF >= W * 1024 ? NSLOT * XBUF : W * 1024;  // the x buffers double as the epilogue's per-wave transposition scratch
-    __shared__ __attribute__((aligned(16))) uint32_t lut[C1::LDS_DWORDS];
-    __shared__ __attribute__((aligned(16))) unsigned char xt[XT];
+    // ONE block, the codebook image FIRST: at LDS address 0 a gather address is one v_and_or_b32 (hash bits | copy of this lane); as two
+    // arrays the compiler put the tiles first and every gather paid a v_and_b32 + v_add_u32 (32 more vector instructions per step)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C1::LDS_DWORDS * 4 + XT];
+    uint32_t *const lut = reinterpret_cast<uint32_t *>(smem);
+    unsigned char *const xt = smem + C1::LDS_DWORDS * 4;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
