@@ -11,8 +11,12 @@ template <int S, int KV1, int KV2, int NBG, int ROT = 0>
 static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
     [[maybe_unused]] const TcParams &p = mp.job[0];
     const TcEarly e = early_args(mp);
-    using C1 = TcqCodec<S, KV1>;
-    using C2 = std::conditional_t<KV2 == 0, void, TcqCodec<S, KV2 == 0 ? KV1 : KV2>>;
+#ifndef QPAL_TCQ_XS  // (experiment: 1 = the conflict-free 32-copy codebook image, 128 KiB, for the 1024-entry codebooks)
+#define QPAL_TCQ_XS 0
+#endif
+    constexpr int XS = (QPAL_TCQ_XS != 0 && S == 9) ? 1 : 0;
+    using C1 = TcqCodec<S, KV1, XS>;
+    using C2 = std::conditional_t<KV2 == 0, void, TcqCodec<S, KV2 == 0 ? KV1 : KV2, XS>>;
 #ifdef QPAL_STAMPS
     // QPAL_STAMPS_BUF=<device address>: EVERY launch stamps into a caller-owned buffer (slot per launch shape: 8 slots of
     // 256 x 16 x 8 u64), also inside a captured graph — the steady-state timeline of a replayed token (perf/stamps_replay.py)
