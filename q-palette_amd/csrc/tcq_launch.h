@@ -23,7 +23,7 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
     if (const char *sb = getenv("QPAL_STAMPS_BUF")) {
         static int keys[8] = {0};
         static int nkeys = 0;
-        const int key = grid * 131 + p.k + ROT * 7 + 1;
+        const int key = grid * 131 + p.k + ROT * 7 + 1 + p.nrows * 1009;
         int slot = -1;
         for (int i = 0; i < nkeys; i++)
             if (keys[i] == key) slot = i;
@@ -44,9 +44,9 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
     static int seen[8] = {0};
     static int nseen = 0;
     bool fresh = true;
-    for (int i = 0; i < nseen; i++) fresh = fresh && seen[i] != grid * 131 + p.k;
+    for (int i = 0; i < nseen; i++) fresh = fresh && seen[i] != grid * 131 + p.k + p.nrows * 1009;
     if (fresh && nseen < 8) {
-        seen[nseen++] = grid * 131 + p.k;
+        seen[nseen++] = grid * 131 + p.k + p.nrows * 1009;
         TcParams q = p;
         unsigned long long *d = nullptr;
         const size_t nb = (size_t)grid * 16 * 8 * sizeof(unsigned long long);
@@ -83,6 +83,20 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
         const char *nm[8] = {"", "issue-w", "x+lut", "barrier", "steps", "xor-red", "barrier2", "final"};
         for (int i = 1; i < 8; i++) printf(" %s %.2f/%.2f", nm[i], ph[i] / (nw ? nw : 1) / 100.0, phmax[i] / 100.0);
         printf("\n");
+        {   // by wave index inside the workgroup (waves w, w + 4, ... share a SIMD; lower index = older): steps of the wave, length of its steps phase, when it ended
+            double len[16] = {0}, end[16] = {0};
+            int cnt[16] = {0};
+            for (int w = 0; w < grid * 16; w++) {
+                if (!h[w * 8] || !h[w * 8 + 7] || !h[w * 8 + 4] || !h[w * 8 + 3]) continue;
+                len[w & 15] += (double)(h[w * 8 + 4] - h[w * 8 + 3]);
+                end[w & 15] += (double)(h[w * 8 + 4] - t0);
+                cnt[w & 15]++;
+            }
+            printf("[stamps]   wave: steps / steps phase us / ended at us:");
+            for (int w = 0; w < 16; w++)
+                if (cnt[w]) printf(" %d: %d / %.2f / %.2f |", w, (int)(mp.plan[0].w[0][w].b >> 16), len[w] / cnt[w] / 100.0, end[w] / cnt[w] / 100.0);
+            printf("\n");
+        }
         if (const char *dump = getenv("QPAL_STAMPS_DUMP")) {  // raw stamps for offline analysis: one binary file per stamped launch
             char path[512];
             snprintf(path, sizeof path, "%s_%s_grid%d_m%d_k%d.bin", dump, ROT ? "rot" : "plain", grid, p.nrows * 32, p.k);
