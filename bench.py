@@ -1077,6 +1077,9 @@ OTHER_CONFIGS = [  # (key, workload, batch): BASELINE.json configs[2], [3] (both
     ("llama3.1-8b_figure1c", "llama3.1-8b_figure1c", 1),
     ("llama3.1-70b_tcq_6_bs1", "llama3.1-70b_tcq_6", 1),
     ("llama3.1-70b_tcq_6_bs16", "llama3.1-70b_tcq_6", 16),
+    # the batched fused path (north_star "MFMA ... batched dequant-then-GEMM") on the headline model: one launch per projection group
+    ("llama3.1-8b_tcomb_6_7_bs64", "llama3.1-8b_tcomb_6_7", 64),
+    ("llama3.1-8b_tcomb_6_7_bs128", "llama3.1-8b_tcomb_6_7", 128),
 ]
 
 

@@ -40,11 +40,12 @@ def test_bench_prints_one_contract_line(monkeypatch):
     w = d["with_incoherence_wrapper"]
     assert "error" not in w and 0 < w["value"] < d["value"]
     oc = d["other_configs"]  # BASELINE configs[2..4] in the driver-timed line (2-layer models here)
-    assert set(oc) == {"llama3.1-8b_mem3p25", "llama3.1-8b_figure1d", "llama3.1-8b_figure1c", "llama3.1-70b_tcq_6_bs1", "llama3.1-70b_tcq_6_bs16"}
+    assert set(oc) == {"llama3.1-8b_mem3p25", "llama3.1-8b_figure1d", "llama3.1-8b_figure1c", "llama3.1-70b_tcq_6_bs1", "llama3.1-70b_tcq_6_bs16",
+                       "llama3.1-8b_tcomb_6_7_bs64", "llama3.1-8b_tcomb_6_7_bs128"}  # + the batched path on the headline model
     for key, fig in oc.items():
         assert "error" not in fig, (key, fig)
         assert fig["unit"] == "tokens/s" and fig["value"] > 0 and fig["ms_per_step"] > 0 and 0 < fig["frac"] < 1 and fig["steps"] <= 10
-        assert fig["batch"] == (16 if key.endswith("bs16") else 1) and fig["layers"] == 2
+        assert fig["batch"] == (int(key.rsplit("_bs", 1)[1]) if "_bs" in key else 1) and fig["layers"] == 2
     rs = d["config"]["ranks_seen"]
     assert rs["world_size"] == 1 and rs["distinct_devices"] == 1 and rs["ranks"][0]["rank"] == 0 and rs["ranks"][0]["pci_bus_id"]
     wm = d["whole_model_decode"]  # the reference's own metric (whole-model decode step), measured after the headline
