@@ -300,7 +300,7 @@ def make_token(qp, torch, layers, xs, n, device, launch="multi", no_prezero=Fals
         return outs
 
     # Batch 1..3, multi-job launches: the harness owns the outputs here too — one block per launch, zeroed by the launch before it
-    # (prezero), so that the library may share rows between workgroups (pair mode) or split K wherever that fills the chip,
+    # (prezero), so that the library's launch planner may share rows between workgroups or split K wherever that fills the chip,
     # without a memset node of its own.  The first launch of a token has no predecessor: its outputs are not declared zeroed.
     # (Round 4: per GROUP — a mixed-scheme model's groups of tensor-core-order layers get owned, pre-zeroed outputs although other
     # groups of the model are SIMT-packed: their single-codec gate | up launches then pair like the uniform model's.)
@@ -950,8 +950,8 @@ def main():
                    "linears_per_token": nlinear, "launches_per_token": nlaunch, "phases_per_token": nphase,
                    "launch_mode": args.launch,
                    "outputs": ("fresh per launch (--no-prezero): the library adds a memset node where it splits K" if args.no_prezero else
-                               "owned by the harness, every launch zeroes the next launch's block (the library may split K / pair "
-                               "workgroups without memset nodes; QPAL_PAIR=" + os.environ.get("QPAL_PAIR", "1") + ")"),
+                               "owned by the harness, every launch zeroes the next launch's block (the library may split K / share rows "
+                               "between workgroups without memset nodes; QPAL_SHARE=" + os.environ.get("QPAL_SHARE", os.environ.get("QPAL_PAIR", "1")) + ")"),
                    "incoherent": bool(args.incoherent),
                    "rotation_launches_per_token": nrot[0] if args.incoherent else 0,
                    "ranks_seen": ranks_seen},

@@ -57,8 +57,8 @@ typedef struct qpal_tcq_job {
     const void *tlut;  /* fp16 [2^S][2] */
     int m, k;
     int out_zeroed;    /* 1: the caller guarantees out is all zeros (e.g. pre-zeroed by an earlier launch, below):
-                          a split-K job then needs no memset node of its own, and the planner may let two workgroups share
-                          a row (pair mode, csrc/tc_kernels.h TcParams: +3 % tokens/s on a Llama-8B token) — both use
+                          a split-K job then needs no memset node of its own, and the launch planner may let two workgroups share
+                          a row (csrc/qpal_capi.hip plan_launch, DESIGN.md §4.2: +3 % tokens/s on a Llama-8B token) — both use
                           float atomics into the zeroed buffer; with at most two adders per element of a ZEROED output the
                           result is order-independent (0 + a + b).  A job that accumulates (`accumulate`: out += ...) may be
                           split or paired as well: its adders land on the live value h, and (h + a) + b != (h + b) + a in
