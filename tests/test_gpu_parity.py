@@ -479,6 +479,37 @@ def test_ragged_shapes(qp, oracle, m, k):
             _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle, fp16_out=twin)
 
 
+@pytest.mark.parametrize("m,k", RAGGED)
+def test_ragged_shapes_batched(qp, oracle, m, k):
+    """The same ragged shapes through the lockstep skinny-GEMM kernels (batches 9..16: csrc/tc_gemm.h; 17..128: csrc/tc_gemm16.h —
+    16 real rows of W per MFMA): partial steps, row groups with dead waves (m / 32 not a multiple of 8), K ranges shorter than the
+    K split, batch rows that do not fill a group of 16; then the epilogue forms at a wide batch — per-row scale, output scale,
+    residual add — on the multi-job entry point."""
+    gen = torch.Generator().manual_seed(m * 11 + k)
+    cases = ["tcq_6_none_0.9", "ldlq_2_8_none_1.0"]
+    if k % 64 == 0:
+        cases.append("tcomb_6_7_0.5_none_0.9")
+    for qstr in cases:
+        info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=m + k + 1)
+        layer = qp.make_linear_from_info(qstr, info).cuda()
+        W = _oracle_weight(oracle, qstr, info, m, k)
+        for n in (12, 17, 40, 128):
+            x = torch.randn(n, k, generator=gen).half()
+            y = layer._gemv(x.cuda(), n)
+            assert y.dtype == torch.float32 and tuple(y.shape) == (n, m)
+            _check_gemv(y.cpu().numpy(), W, x.numpy(), oracle)
+        n = 33
+        x = torch.randn(n, k, generator=gen).half()
+        ws = (torch.rand(m, generator=gen) + 0.5).half()
+        base = torch.randn(n, m, generator=gen)
+        out = base.clone().cuda()
+        qp.multi_gemv([layer], x.cuda(), outs=[out], wscales=[ws.cuda()], oscale=0.75, accumulate=True)
+        ref, scale = oracle.gemv(W, x.numpy())
+        want = base.numpy().astype(np.float64) + ref * ws.float().numpy().astype(np.float64)[None, :] * 0.75
+        tol = GEMV_RTOL_ABS * scale * ws.float().numpy()[None, :] * 0.75 + 1e-6 * np.abs(want) + 1e-30
+        assert np.all(np.abs(out.cpu().numpy().astype(np.float64) - want) <= tol), qstr
+
+
 def test_unsupported_shapes_raise(qp):
     with pytest.raises(AttributeError):
         qp.ops.get_op("decompress_gemm_tcq_48_1_64_9_6")      # m % 32
