@@ -391,6 +391,32 @@ def _check_plan(d, rows, st1, st2, waves):
     return busiest
 
 
+def test_gemv_launch_planner_random_sweep():
+    """400 seeded random launches (1..4 jobs of 1..2000 supertile rows, 1..448 steps, one or two streams, at most two geometry
+    classes, outputs zeroed or not, 16- and 8-wave workgroups) through the planner: every table covers every step of every row
+    exactly once, never more than two workgroups per row, and one launch round never plans more items than it may."""
+    import random
+    rng = random.Random(20261005)
+    for case in range(400):
+        waves = 16 if rng.random() < 0.8 else 8
+        geoms = []
+        for _ in range(rng.choice((1, 1, 2))):
+            a = rng.choice((1, 2, 3, 5, 8, 16, 32, 56, 64, 112, 224, 448, rng.randint(1, 448)))
+            geoms.append((a, rng.choice((0, 0, a))))
+        njobs = rng.randint(1, 4)
+        rows = [rng.choice((1, 2, 7, 32, 128, 448, 896, rng.randint(1, 2000))) for _ in range(njobs)]
+        pick = [rng.randrange(len(geoms)) for _ in range(njobs)]
+        s1, s2 = [geoms[g][0] for g in pick], [geoms[g][1] for g in pick]
+        flags = [rng.randint(0, 1) for _ in range(njobs)]
+        d = _plan(rows, s1, s2, flags, waves=waves)
+        try:
+            _check_plan(d, rows, s1, s2, waves)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: rows {rows} steps {s1} + {s2} flags {flags} waves {waves}: {e}") from e
+        for j in range(njobs):
+            assert d["jobs"][j]["sk"] in (1, 2) and (flags[j] or d["jobs"][j]["sk"] in (1, 2))
+
+
 def test_gemv_launch_planner_tables():
     """The host-side launch planner of the fused GEMV (csrc/qpal_capi.hip plan_launch, C-ABI qpal_plan_gemv): its per-wave tables
     cover every step of every row exactly once for the shapes the workloads launch, keep to two workgroups per row, and reach the
