@@ -510,6 +510,37 @@ def test_ragged_shapes_batched(qp, oracle, m, k):
         assert np.all(np.abs(out.cpu().numpy().astype(np.float64) - want) <= tol), qstr
 
 
+def test_random_shapes_fuzz(qp, oracle):
+    """48 seeded random (family, m, k, batch) cases against the oracle: whatever the launch planner (batch <= 8) or the lockstep
+    kernels' K split and batch slices (batch > 8) make of an unusual shape must still be the same GEMV."""
+    import random
+    rng = random.Random(5)
+    fams = ["tcq_3_none_0.9", "tcq_5_none_0.9", "tcq_6_none_0.9", "tcq_8_none_0.9", "tcq_10_none_0.9", "tcomb_3_4_0.5_none_0.9",
+            "tcomb_6_7_0.5_none_0.9", "tcomb_9_10_0.5_none_0.9", "ldlq_1_3_none_1.0", "ldlq_1_8_none_1.0", "ldlq_2_6_none_1.0", "ldlq_2_11_none_1.0"]
+    done = 0
+    while done < 48:
+        qstr = rng.choice(fams)
+        m = 32 * rng.choice((1, 2, 3, 5, 8, 9, 17, 31, 40, 64, 96))
+        k = 64 * rng.choice((1, 2, 3, 5, 8, 13, 16, 33, 64, 100, 128))
+        n = rng.choice((1, 2, 3, 5, 8, 9, 13, 16, 17, 33, 48, 64, 65, 100, 128))
+        if m * k * n > 3e8:
+            continue
+        if qstr.startswith("ldlq_2_") and (int(qstr.split("_")[2]) * k) % 64:
+            continue
+        info = qp.mem_op.dummy_linear_info(k, m, qstr, seed=1000 + done)
+        layer = qp.make_linear_from_info(qstr, info).cuda()
+        if n > layer.max_fused_batch:
+            continue
+        W = _oracle_weight(oracle, qstr, info, m, k)
+        x = torch.randn(n, k, generator=torch.Generator().manual_seed(done)).half()
+        y = layer._gemv(x.cuda(), n)
+        try:
+            _check_gemv(y.float().cpu().numpy(), W, x.numpy(), oracle, fp16_out=y.dtype == torch.float16)
+        except AssertionError as e:
+            raise AssertionError(f"{qstr} m {m} k {k} n {n}: {e}") from e
+        done += 1
+
+
 def test_unsupported_shapes_raise(qp):
     with pytest.raises(AttributeError):
         qp.ops.get_op("decompress_gemm_tcq_48_1_64_9_6")      # m % 32
