@@ -158,6 +158,50 @@ __device__ __forceinline__ GemmStep gemm_where(const TcParams &p, int g) {
     return r;
 }
 
+// ---- buffer-addressed loads of the lockstep kernels (round 5).  The step loop is vector-issue bound (SQ counters of the 70B batch-16
+// kernel: the issue port 88 % busy, profiles/r05_ab_batched_path.txt §10), and with flat addresses every step paid 64-bit address
+// arithmetic for its tile chunk and its weights (v_lshl_add_u64 x 3, v_mad_u64_u32, clamps by v_cndmask: ~14 of 155 vector instructions,
+// most of them quarter-rate) plus the copy of the prefetched weights into the current registers.  With buffer descriptors built once
+// per item (x: the whole [n][k] block; weights: this wave's row of each stream) a load's address is ONE 32-bit add to a per-thread
+// offset, and the range check of the descriptor does the clamping: batch rows >= n, supertile columns past the end of a stream and
+// the re-read of dead chunks all return zeros (the per-step part is added to the VECTOR offset: the scalar offset is not range-checked).
+using buf_rsrc_t = __amdgpu_buffer_rsrc_t;
+template <class T>
+__device__ __forceinline__ buf_rsrc_t gemm_rsrc(const T *base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base), (short)0, bytes, 0x00020000);
+}
+constexpr uint32_t kBufDead = 0x7fffff00u;  // a vector offset beyond every descriptor's range (num_records < 2^31)
+// NW consecutive dwords at byte offset voff of the descriptor, non-temporal (streamed-once weights)
+template <int NW>
+__device__ __forceinline__ void buf_load_words_nt(buf_rsrc_t rs, uint32_t voff, uint32_t (&w)[NW]) {
+    constexpr int Q = NW / 4, R = NW % 4;
+    static_for<0, Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * q, 0, 2);
+        w[4 * q + 0] = v.x;
+        w[4 * q + 1] = v.y;
+        w[4 * q + 2] = v.z;
+        w[4 * q + 3] = v.w;
+    });
+    if constexpr (R == 3) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b96(rs, voff + 16 * Q, 0, 2);
+        w[4 * Q + 0] = v[0];
+        w[4 * Q + 1] = v[1];
+        w[4 * Q + 2] = v[2];
+    } else if constexpr (R == 2) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 16 * Q, 0, 2);
+        w[4 * Q + 0] = v[0];
+        w[4 * Q + 1] = v[1];
+    } else if constexpr (R == 1) {
+        w[4 * Q] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 16 * Q, 0, 2);
+    }
+}
+// this lane's byte offset inside its row of a stream, for step 0: supertile lane >> 4, 16 x NW dwords per supertile
+template <int NW>
+__device__ __forceinline__ uint32_t gemm_w_lane_off(int lane) { return ((uint32_t)(lane >> 4) * 16u * NW + (uint32_t)(lane & 15) * NW) * 4u; }
+template <int NW>
+constexpr uint32_t gemm_w_step_bytes() { return 4u * 16u * NW * 4u; }  // four supertiles per step
+
 template <class C1, class C2, int NBG>
 // eie: the launch's item table packed into one PRELOADED dword (gemm_item_table; tc_kernels.h early_args does the same for the GEMV
 // kernels): a workgroup knows the job of its first item before the kernel-argument block has arrived and fetches THAT job's
@@ -234,10 +278,20 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const int eie,
 
         uint32_t wcur[NWMAX], wnext[NWMAX];
         u32x4 xr[CPT];
+        const buf_rsrc_t rs_x = gemm_rsrc(p.x, p.n * p.k * 2);
+        const buf_rsrc_t rs_w1 = gemm_rsrc(sv1.base, sv1.nsc * 64 * C1::NW);
+        const buf_rsrc_t rs_w2 = gemm_rsrc(sv2.base, sv2.nsc * 64 * CB::NW);
+        const uint32_t wl1 = gemm_w_lane_off<C1::NW>(lane), wl2 = gemm_w_lane_off<CB::NW>(lane);
+        uint32_t xvo[CPT];  // byte offset of this thread's chunk r inside x, without the step's column base
+#pragma unroll
+        for (int r = 0; r < CPT; r++) {
+            const int id = tid + r * NT, b = id >> 4;
+            xvo[r] = (id < NCH && b < p.n) ? (uint32_t)(b * p.k + 8 * (id & 15)) * 2u : kBufDead;
+        }
         auto load_w = [&](int g, uint32_t(&dst)[NWMAX]) {
             const GemmStep st = gemm_where(p, g);
-            if (TWO && st.on2) load_step_w<CB::NW>(sv2, st.s, lane, reinterpret_cast<uint32_t(&)[CB::NW]>(dst));
-            else load_step_w<C1::NW>(sv1, st.s, lane, reinterpret_cast<uint32_t(&)[C1::NW]>(dst));
+            if (TWO && st.on2) buf_load_words_nt<CB::NW>(rs_w2, wl2 + (uint32_t)st.s * gemm_w_step_bytes<CB::NW>(), reinterpret_cast<uint32_t(&)[CB::NW]>(dst));
+            else buf_load_words_nt<C1::NW>(rs_w1, wl1 + (uint32_t)st.s * gemm_w_step_bytes<C1::NW>(), reinterpret_cast<uint32_t(&)[C1::NW]>(dst));
         };
         // chunk id -> (batch row b = id >> 4, 16-byte piece q = id & 15 of the step's 128 columns)
         // (unconditional loads from clamped addresses — a dead chunk re-reads x[0..7] and is zeroed when it is stored: a load under a
@@ -247,15 +301,10 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const int eie,
             const int id = tid + r * NT;
             return id < NCH && (id >> 4) < p.n && st.col_base + 8 * (id & 15) < st.col_end;
         };
-        auto load_x = [&](int g) {
+        auto load_x = [&](int g) {  // (columns past the end of the stream are zeroed when the chunk is stored: x_live)
             const GemmStep st = gemm_where(p, g);
 #pragma unroll
-            for (int r = 0; r < CPT; r++) {
-                const int id = tid + r * NT;
-                const int b = id >> 4, col = st.col_base + 8 * (id & 15);
-                const bool ok = id < NCH && b < p.n && col < st.col_end;
-                xr[r] = *reinterpret_cast<const u32x4 *>(p.x + (ok ? (long)b * p.k + col : 0l));
-            }
+            for (int r = 0; r < CPT; r++) xr[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xvo[r] + (uint32_t)st.col_base * 2u, 0, 0);
         };
         auto store_x = [&](unsigned char *buf, int g) {
 #pragma unroll
@@ -306,7 +355,7 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const int eie,
         auto run = [&](auto codec_c, int ga, int gb) {
             using CC = typename decltype(codec_c)::type;
             constexpr bool SECOND = TWO && std::is_same_v<CC, CB> && !std::is_same_v<C1, CB>;
-            for (int g = ga; g < gb; g++) {
+            auto one_step = [&](int g, uint32_t(&wc)[NWMAX], uint32_t(&wn)[NWMAX]) {
                 // Round 4: the tile FIRST (it is stored to LDS at the end of this step; the weights are next step's), and the weight
                 // prefetch without a branch — the next step of THIS stream, the last one re-requesting itself; the first step of
                 // the other stream is requested by the caller at the switch.  With the codec branch of load_w and the predicated
@@ -316,24 +365,30 @@ __global__ __launch_bounds__(64 * kGemmWaves) void tc_gemm_kernel(const int eie,
                 if constexpr (!(QPAL_GEMM_KO & 4)) load_x(xg);
                 if constexpr (QPAL_GEMM_KO & 32) {
 #pragma unroll
-                    for (int i = 0; i < NWMAX; i++) wnext[i] = wcur[i] + 1;
+                    for (int i = 0; i < NWMAX; i++) wn[i] = wc[i] + 1;
                 } else {
                     const int gn = g + 1 < gb ? g + 1 : g;
-                    if constexpr (SECOND) load_step_w<CC::NW>(sv2, gn - p.st1, lane, reinterpret_cast<uint32_t(&)[CC::NW]>(wnext));
-                    else load_step_w<CC::NW>(sv1, gn, lane, reinterpret_cast<uint32_t(&)[CC::NW]>(wnext));
+                    if constexpr (SECOND) buf_load_words_nt<CC::NW>(rs_w2, wl2 + (uint32_t)(gn - p.st1) * gemm_w_step_bytes<CC::NW>(), reinterpret_cast<uint32_t(&)[CC::NW]>(wn));
+                    else buf_load_words_nt<CC::NW>(rs_w1, wl1 + (uint32_t)gn * gemm_w_step_bytes<CC::NW>(), reinterpret_cast<uint32_t(&)[CC::NW]>(wn));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const int i = g - g0;
                 if (live)  // (wave-uniform: a row past the end of the layer only keeps the staging and the barriers company)
-                    gemm_step<CC, NBG>(lut, laneoff, reinterpret_cast<uint32_t(&)[CC::NW]>(wcur), xt + (i & (NSLOT - 1)) * XBUF, lane, acc);
+                    gemm_step<CC, NBG>(lut, laneoff, reinterpret_cast<uint32_t(&)[CC::NW]>(wc), xt + (i & (NSLOT - 1)) * XBUF, lane, acc);
                 // slot of step i + AHEAD: last read AHEAD steps ago, i.e. before the latest barrier
                 if constexpr (!(QPAL_GEMM_KO & 4)) store_x(xt + ((i + AHEAD) & (NSLOT - 1)) * XBUF, xg);
                 if constexpr (!(QPAL_GEMM_KO & 8)) {
                     if (AHEAD == 1 || (i & 1)) __syncthreads();
                 }
-#pragma unroll
-                for (int i = 0; i < NWMAX; i++) wcur[i] = wnext[i];
+            };
+            // two steps per trip: the prefetched weights become the current ones by NAME (no register copies); an odd count ends on a
+            // single step, and whoever continues (the other stream's run) loads its first step into wcur itself
+            int g = ga;
+            for (; g + 1 < gb; g += 2) {
+                one_step(g, wcur, wnext);
+                one_step(g + 1, wnext, wcur);
             }
+            if (g < gb) one_step(g, wcur, wnext);
         };
         if constexpr (!(QPAL_GEMM_KO & 256)) {
             const int mid = g1 < p.st1 ? g1 : (g0 > p.st1 ? g0 : p.st1);

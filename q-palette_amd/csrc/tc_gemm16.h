@@ -266,22 +266,28 @@ __global__ __launch_bounds__(64 * kG16Waves) void tc_gemm16_kernel(const int eie
 
         uint32_t wcur[NWMAX], wnext[NWMAX];
         u32x4 xr[CPT];
+        // buffer-addressed loads (tc_gemm.h): one 32-bit add per load and step, the descriptors' range checks do the clamping
+        const buf_rsrc_t rs_x = gemm_rsrc(p.x, p.n * p.k * 2);
+        const buf_rsrc_t rs_w1 = gemm_rsrc(sv1.base, sv1.nsc * 64 * C1::NW);
+        const buf_rsrc_t rs_w2 = gemm_rsrc(sv2.base, sv2.nsc * 64 * CB::NW);
+        const uint32_t wl1 = gemm_w_lane_off<C1::NW>(lane), wl2 = gemm_w_lane_off<CB::NW>(lane);
+        uint32_t xvo[CPT];  // byte offset of this thread's chunk r inside x, without the step's column base
+#pragma unroll
+        for (int r = 0; r < CPT; r++) {
+            const int id = tid + r * NT, b = id >> 4;
+            xvo[r] = (id < NCH && b < p.n) ? (uint32_t)(b * p.k + 8 * g16_chunk_q(id & 15)) * 2u : kBufDead;
+        }
         auto load_w = [&](int g, uint32_t(&dst)[NWMAX]) {
             const GemmStep st = gemm_where(p, g);
-            if (TWO && st.on2) load_step_w<CB::NW>(sv2, st.s, lane, reinterpret_cast<uint32_t(&)[CB::NW]>(dst));
-            else load_step_w<C1::NW>(sv1, st.s, lane, reinterpret_cast<uint32_t(&)[C1::NW]>(dst));
+            if (TWO && st.on2) buf_load_words_nt<CB::NW>(rs_w2, wl2 + (uint32_t)st.s * gemm_w_step_bytes<CB::NW>(), reinterpret_cast<uint32_t(&)[CB::NW]>(dst));
+            else buf_load_words_nt<C1::NW>(rs_w1, wl1 + (uint32_t)st.s * gemm_w_step_bytes<C1::NW>(), reinterpret_cast<uint32_t(&)[C1::NW]>(dst));
         };
         // chunk id -> (batch row b = id >> 4, 16-byte piece q = id & 15 of the step's 128 columns); unconditional loads from clamped
         // addresses, dead chunks zeroed when stored (tc_gemm.h: a load under a condition makes the compiler's wait counts conservative)
-        auto load_x = [&](int g) {
+        auto load_x = [&](int g) {  // (columns past the end of the stream are zeroed when the chunk is stored)
             const GemmStep st = gemm_where(p, g);
 #pragma unroll
-            for (int r = 0; r < CPT; r++) {
-                const int id = tid + r * NT;
-                const int b = id >> 4, col = st.col_base + 8 * g16_chunk_q(id & 15);
-                const bool ok = id < NCH && b < p.n && col < st.col_end;
-                xr[r] = *reinterpret_cast<const u32x4 *>(p.x + (ok ? (long)b * p.k + col : 0l));
-            }
+            for (int r = 0; r < CPT; r++) xr[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xvo[r] + (uint32_t)st.col_base * 2u, 0, 0);
         };
         auto store_x = [&](unsigned char *buf, int g) {
             const GemmStep st = gemm_where(p, g);
@@ -327,23 +333,27 @@ __global__ __launch_bounds__(64 * kG16Waves) void tc_gemm16_kernel(const int eie
         auto run = [&](auto codec_c, int ga, int gb) {
             using CC = typename decltype(codec_c)::type;
             constexpr bool SECOND = TWO && std::is_same_v<CC, CB> && !std::is_same_v<C1, CB>;
-            for (int g = ga; g < gb; g++) {
+            auto one_step = [&](int g, uint32_t(&wc)[NWMAX], uint32_t(&wn)[NWMAX]) {
                 const int xg = g + AHEAD < g1 ? g + AHEAD : g1 - 1;
                 if constexpr (!(QPAL_GEMM_KO & 4)) load_x(xg);
                 const int gn = g + 1 < gb ? g + 1 : g;
-                if constexpr (SECOND) load_step_w<CC::NW>(sv2, gn - p.st1, lane, reinterpret_cast<uint32_t(&)[CC::NW]>(wnext));
-                else load_step_w<CC::NW>(sv1, gn, lane, reinterpret_cast<uint32_t(&)[CC::NW]>(wnext));
+                if constexpr (SECOND) buf_load_words_nt<CC::NW>(rs_w2, wl2 + (uint32_t)(gn - p.st1) * gemm_w_step_bytes<CC::NW>(), reinterpret_cast<uint32_t(&)[CC::NW]>(wn));
+                else buf_load_words_nt<CC::NW>(rs_w1, wl1 + (uint32_t)gn * gemm_w_step_bytes<CC::NW>(), reinterpret_cast<uint32_t(&)[CC::NW]>(wn));
                 __builtin_amdgcn_sched_barrier(0);
                 const int i = g - g0;
                 if (live)  // (wave-uniform: a row past the end of the layer only keeps the staging and the barriers company)
-                    g16_step<CC, NG>(lut, laneoff, reinterpret_cast<uint32_t(&)[CC::NW]>(wcur), xt + (i & (NSLOT - 1)) * XBUF, lane, acc);
+                    g16_step<CC, NG>(lut, laneoff, reinterpret_cast<uint32_t(&)[CC::NW]>(wc), xt + (i & (NSLOT - 1)) * XBUF, lane, acc);
                 if constexpr (!(QPAL_GEMM_KO & 4)) store_x(xt + ((i + AHEAD) & (NSLOT - 1)) * XBUF, xg);  // slot of step i + AHEAD: last read before the latest barrier
                 if constexpr (!(QPAL_GEMM_KO & 8)) {
                     if (AHEAD == 1 || (i & 1)) __syncthreads();
                 }
-#pragma unroll
-                for (int q = 0; q < NWMAX; q++) wcur[q] = wnext[q];
+            };
+            int g = ga;  // two steps per trip: the prefetched weights become the current ones by name (tc_gemm.h)
+            for (; g + 1 < gb; g += 2) {
+                one_step(g, wcur, wnext);
+                one_step(g + 1, wnext, wcur);
             }
+            if (g < gb) one_step(g, wcur, wnext);
         };
         const int mid = g1 < p.st1 ? g1 : (g0 > p.st1 ? g0 : p.st1);
         if constexpr (!(QPAL_GEMM_KO & 256)) {
