@@ -165,43 +165,7 @@ __device__ __forceinline__ GemmStep gemm_where(const TcParams &p, int g) {
 // per item (x: the whole [n][k] block; weights: this wave's row of each stream) a load's address is ONE 32-bit add to a per-thread
 // offset, and the range check of the descriptor does the clamping: batch rows >= n, supertile columns past the end of a stream and
 // the re-read of dead chunks all return zeros (the per-step part is added to the VECTOR offset: the scalar offset is not range-checked).
-using buf_rsrc_t = __amdgpu_buffer_rsrc_t;
-template <class T>
-__device__ __forceinline__ buf_rsrc_t gemm_rsrc(const T *base, int bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base), (short)0, bytes, 0x00020000);
-}
-constexpr uint32_t kBufDead = 0x7fffff00u;  // a vector offset beyond every descriptor's range (num_records < 2^31)
-// NW consecutive dwords at byte offset voff of the descriptor, non-temporal (streamed-once weights)
-template <int NW>
-__device__ __forceinline__ void buf_load_words_nt(buf_rsrc_t rs, uint32_t voff, uint32_t (&w)[NW]) {
-    constexpr int Q = NW / 4, R = NW % 4;
-    static_for<0, Q>([&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * q, 0, 2);
-        w[4 * q + 0] = v.x;
-        w[4 * q + 1] = v.y;
-        w[4 * q + 2] = v.z;
-        w[4 * q + 3] = v.w;
-    });
-    if constexpr (R == 3) {
-        const auto v = __builtin_amdgcn_raw_buffer_load_b96(rs, voff + 16 * Q, 0, 2);
-        w[4 * Q + 0] = v[0];
-        w[4 * Q + 1] = v[1];
-        w[4 * Q + 2] = v[2];
-    } else if constexpr (R == 2) {
-        const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 16 * Q, 0, 2);
-        w[4 * Q + 0] = v[0];
-        w[4 * Q + 1] = v[1];
-    } else if constexpr (R == 1) {
-        w[4 * Q] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 16 * Q, 0, 2);
-    }
-}
-// this lane's byte offset inside its row of a stream, for step 0: supertile lane >> 4, 16 x NW dwords per supertile
-template <int NW>
-__device__ __forceinline__ uint32_t gemm_w_lane_off(int lane) { return ((uint32_t)(lane >> 4) * 16u * NW + (uint32_t)(lane & 15) * NW) * 4u; }
-template <int NW>
-constexpr uint32_t gemm_w_step_bytes() { return 4u * 16u * NW * 4u; }  // four supertiles per step
-
+// (the helpers — buf_rsrc_t, gemm_rsrc, buf_load_words_nt, gemm_w_lane_off, gemm_w_step_bytes — live in tc_kernels.h: the fused GEMV uses them too)
 template <class C1, class C2, int NBG>
 // eie: the launch's item table packed into one PRELOADED dword (gemm_item_table; tc_kernels.h early_args does the same for the GEMV
 // kernels): a workgroup knows the job of its first item before the kernel-argument block has arrived and fetches THAT job's

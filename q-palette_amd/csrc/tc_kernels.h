@@ -414,6 +414,52 @@ __device__ __forceinline__ void load_step_w(const StreamView &sv, int step, int 
     load_words_nt<NW>(sv.base + off, w);
 }
 
+// ---- buffer-addressed weight / tile loads (round 5; first in the lockstep kernels, tc_gemm.h, then here): a descriptor per wave-item,
+// one 32-bit add per load and step instead of 64-bit address arithmetic, the descriptor's range check instead of clamps.
+using buf_rsrc_t = __amdgpu_buffer_rsrc_t;
+template <class T>
+__device__ __forceinline__ buf_rsrc_t gemm_rsrc(const T *base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base), (short)0, bytes, 0x00020000);
+}
+constexpr uint32_t kBufDead = 0x7fffff00u;  // a vector offset beyond every descriptor's range (num_records < 2^31)
+// NW consecutive dwords at byte offset voff of the descriptor, non-temporal (streamed-once weights)
+template <int NW>
+__device__ __forceinline__ void buf_load_words_nt(buf_rsrc_t rs, uint32_t voff, uint32_t (&w)[NW]) {
+    constexpr int Q = NW / 4, R = NW % 4;
+    static_for<0, Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * q, 0, 2);
+        w[4 * q + 0] = v.x;
+        w[4 * q + 1] = v.y;
+        w[4 * q + 2] = v.z;
+        w[4 * q + 3] = v.w;
+    });
+    if constexpr (R == 3) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b96(rs, voff + 16 * Q, 0, 2);
+        w[4 * Q + 0] = v[0];
+        w[4 * Q + 1] = v[1];
+        w[4 * Q + 2] = v[2];
+    } else if constexpr (R == 2) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 16 * Q, 0, 2);
+        w[4 * Q + 0] = v[0];
+        w[4 * Q + 1] = v[1];
+    } else if constexpr (R == 1) {
+        w[4 * Q] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 16 * Q, 0, 2);
+    }
+}
+// this lane's byte offset inside its row of a stream, for step 0: supertile lane >> 4, 16 x NW dwords per supertile
+template <int NW>
+__device__ __forceinline__ uint32_t gemm_w_lane_off(int lane) { return ((uint32_t)(lane >> 4) * 16u * NW + (uint32_t)(lane & 15) * NW) * 4u; }
+template <int NW>
+constexpr uint32_t gemm_w_step_bytes() { return 4u * 16u * NW * 4u; }  // four supertiles per step
+
+// weights of step `step` through a descriptor of the wave's row of the stream (num_records = nsc * 64 * NW bytes: supertile columns
+// past the end read zeros — neutralised by zero activations like the re-read of load_step_w)
+template <int NW>
+__device__ __forceinline__ void load_step_w_buf(buf_rsrc_t rs, int step, int lane, uint32_t (&w)[NW]) {
+    buf_load_words_nt<NW>(rs, gemm_w_lane_off<NW>(lane) + (uint32_t)step * gemm_w_step_bytes<NW>(), w);
+}
+
 // Accumulators of one wave: NBG batch groups (8 batch rows each) x 4 row groups (msub*2 + jl).
 template <int NBG>
 struct Acc {
@@ -571,13 +617,13 @@ __device__ __forceinline__ void gemv_step_any(const uint32_t *lut, uint32_t lane
 // is therefore not load latency a deeper register prefetch recovers.
 template <class Codec, int XLDS, int NBG>
 __device__ __forceinline__ void gemv_run(uint32_t (&w)[Codec::NW], const uint32_t *lut, uint32_t laneoff,
-                                         const StreamView &sv, const uint16_t *xg, const uint16_t *xs, int k, int n,
+                                         const StreamView &sv, buf_rsrc_t rs, const uint16_t *xg, const uint16_t *xs, int k, int n,
                                          int zero_off, int s0, int s1, int lane, Acc<NBG> &acc) {
     uint32_t wb[Codec::NW];
     for (int s = s0; s < s1; s += 2) {
         {
             const int sn = s + 1 < s1 ? s + 1 : s;  // last step re-reads itself (L1 hit, unused)
-            load_step_w<Codec::NW>(sv, sn, lane, wb);
+            load_step_w_buf<Codec::NW>(rs, sn, lane, wb);
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's decode (hipcc sinks it otherwise)
             u32x4 xb[NBG][2];
             load_step_x<XLDS, NBG>(sv, xg, xs, k, n, zero_off, s, lane, xb);
@@ -585,7 +631,7 @@ __device__ __forceinline__ void gemv_run(uint32_t (&w)[Codec::NW], const uint32_
         }
         if (s + 1 < s1) {
             const int sn = s + 2 < s1 ? s + 2 : s + 1;
-            load_step_w<Codec::NW>(sv, sn, lane, w);
+            load_step_w_buf<Codec::NW>(rs, sn, lane, w);
             __builtin_amdgcn_sched_barrier(0);
             u32x4 xb[NBG][2];
             load_step_x<XLDS, NBG>(sv, xg, xs, k, n, zero_off, s + 1, lane, xb);
@@ -992,6 +1038,8 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         const StreamView sv1{c1_j + (long)(live ? sr : 0) * p.nsc1 * 16 * nw1, p.nsc1, 0};
         const StreamView sv2{two_rt ? c2_j + (long)(live ? sr : 0) * p.nsc2 * 16 * nw2 : c1_j, two_rt ? p.nsc2 : p.nsc1,
                              p.col2};
+        // the ONE stream this wave's piece lies in, as a buffer descriptor (weight loads: load_step_w_buf)
+        const buf_rsrc_t rs_w = gemm_rsrc(on2 ? sv2.base : sv1.base, (on2 ? sv2.nsc * nw2 : sv1.nsc * nw1) * 64);
         // Early staging, part 2a: the early loads were issued from inline asm, i.e. outside the compiler's wait-count bookkeeping —
         // wait for them by hand, HERE: ~0.2-0.3 us after the wave's entry they and the kernel arguments have arrived together
         // (perf/first_touch.hip), and from here on every load in flight is one the compiler knows about.  (Requesting the weights
@@ -1059,14 +1107,14 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         if constexpr (ANY) {
             dispatch_kv<C1::S_>(on2 ? kv2_j : kv1_j, [&](auto kc) {
                 constexpr int KVr = decltype(kc)::value;
-                load_step_w<KVr>(on2 ? sv2 : sv1, s0, lane, reinterpret_cast<uint32_t(&)[KVr]>(w.a));
+                load_step_w_buf<KVr>(rs_w, s0, lane, reinterpret_cast<uint32_t(&)[KVr]>(w.a));
             });
         } else {
             if constexpr (TWO) {
-                if (on2) load_step_w<CB::NW>(sv2, s0, lane, w.b);
-                else load_step_w<C1::NW>(sv1, s0, lane, w.a);
+                if (on2) load_step_w_buf<CB::NW>(rs_w, s0, lane, w.b);
+                else load_step_w_buf<C1::NW>(rs_w, s0, lane, w.a);
             } else {
-                load_step_w<C1::NW>(sv1, s0, lane, w.a);
+                load_step_w_buf<C1::NW>(rs_w, s0, lane, w.a);
             }
         }
         QPAL_STAMP(1);  // (the first weights are requested)
@@ -1267,24 +1315,24 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                 using CK = TcqCodec<C1::S_, KVr>;
                 auto &wk = reinterpret_cast<uint32_t(&)[KVr]>(w.a);
                 const StreamView &sv = on2 ? sv2 : sv1;
-                if (NBG == 1 && x_lds) gemv_run<CK, kXL, NBG>(wk, lut, laneoff, sv, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-                else gemv_run<CK, 0, NBG>(wk, lut, laneoff, sv, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                if (NBG == 1 && x_lds) gemv_run<CK, kXL, NBG>(wk, lut, laneoff, sv, rs_w, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else gemv_run<CK, 0, NBG>(wk, lut, laneoff, sv, rs_w, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
             });
         } else
         if constexpr (NBG == 1) {
             if (x_lds) {
-                if constexpr (!TWO) gemv_run<C1, kXL, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-                else if (on2) gemv_run<CB, kXL, 1>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-                else gemv_run<C1, kXL, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                if constexpr (!TWO) gemv_run<C1, kXL, 1>(w.a, lut, laneoff, sv1, rs_w, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else if (on2) gemv_run<CB, kXL, 1>(w.b, lut, laneoff, sv2, rs_w, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else gemv_run<C1, kXL, 1>(w.a, lut, laneoff, sv1, rs_w, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
             } else {
-                if constexpr (!TWO) gemv_run<C1, 0, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-                else if (on2) gemv_run<CB, 0, 1>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-                else gemv_run<C1, 0, 1>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                if constexpr (!TWO) gemv_run<C1, 0, 1>(w.a, lut, laneoff, sv1, rs_w, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else if (on2) gemv_run<CB, 0, 1>(w.b, lut, laneoff, sv2, rs_w, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else gemv_run<C1, 0, 1>(w.a, lut, laneoff, sv1, rs_w, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
             }
         } else {
-            if constexpr (!TWO) gemv_run<C1, 0, NBG>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-                else if (on2) gemv_run<CB, 0, NBG>(w.b, lut, laneoff, sv2, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
-            else gemv_run<C1, 0, NBG>(w.a, lut, laneoff, sv1, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+            if constexpr (!TWO) gemv_run<C1, 0, NBG>(w.a, lut, laneoff, sv1, rs_w, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+                else if (on2) gemv_run<CB, 0, NBG>(w.b, lut, laneoff, sv2, rs_w, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
+            else gemv_run<C1, 0, NBG>(w.a, lut, laneoff, sv1, rs_w, p.x, xs, p.k, p.n, zero_off, s0, s1, lane, acc);
         }
         QPAL_STAMP(4);
 
