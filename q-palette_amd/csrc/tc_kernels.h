@@ -620,13 +620,36 @@ __device__ __forceinline__ void gemv_run(uint32_t (&w)[Codec::NW], const uint32_
                                          const StreamView &sv, buf_rsrc_t rs, const uint16_t *xg, const uint16_t *xs, int k, int n,
                                          int zero_off, int s0, int s1, int lane, Acc<NBG> &acc) {
     uint32_t wb[Codec::NW];
+    // Permuted staged x (XLDS == 2, batch 1..8 in one group): the lane's B operand of step s sits 256 bytes behind that of step s - 1, and
+    // the lane's supertile column is past the end of the stream from ONE step on — a per-lane address and a per-lane step bound
+    // worked out once per piece leave three vector instructions per step (add, compare, select) where the general form below spent
+    // eight (round 5: the steps are vector-issue bound).
+    [[maybe_unused]] const char *xl = nullptr, *xz = nullptr;
+    [[maybe_unused]] int dead = 0;
+    if constexpr (XLDS == 2 && NBG == 1) {
+        const int c = lane & 15;
+        int b = c >> 1;
+        b = b < n ? b : n - 1;
+        xl = reinterpret_cast<const char *>(xs) + (b * k + sv.col0 + (lane >> 4) * 32 + 16 * (c & 1)) * 2;
+        xz = reinterpret_cast<const char *>(xs) + zero_off * 2;
+        dead = (sv.nsc - (lane >> 4) + 3) >> 2;  // first step whose supertile column 4 s + (lane >> 4) is >= nsc
+    }
+    auto step_x = [&](int s, u32x4(&xb)[NBG][2]) {
+        if constexpr (XLDS == 2 && NBG == 1) {
+            const char *row = s < dead ? xl + s * 256 : xz;
+            xb[0][0] = *reinterpret_cast<const u32x4 *>(row);
+            xb[0][1] = *reinterpret_cast<const u32x4 *>(row + 16);
+        } else {
+            load_step_x<XLDS, NBG>(sv, xg, xs, k, n, zero_off, s, lane, xb);
+        }
+    };
     for (int s = s0; s < s1; s += 2) {
         {
             const int sn = s + 1 < s1 ? s + 1 : s;  // last step re-reads itself (L1 hit, unused)
             load_step_w_buf<Codec::NW>(rs, sn, lane, wb);
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's decode (hipcc sinks it otherwise)
             u32x4 xb[NBG][2];
-            load_step_x<XLDS, NBG>(sv, xg, xs, k, n, zero_off, s, lane, xb);
+            step_x(s, xb);
             gemv_step_any<Codec, NBG>(lut, laneoff, w, xb, acc);
         }
         if (s + 1 < s1) {
@@ -634,7 +657,7 @@ __device__ __forceinline__ void gemv_run(uint32_t (&w)[Codec::NW], const uint32_
             load_step_w_buf<Codec::NW>(rs, sn, lane, w);
             __builtin_amdgcn_sched_barrier(0);
             u32x4 xb[NBG][2];
-            load_step_x<XLDS, NBG>(sv, xg, xs, k, n, zero_off, s + 1, lane, xb);
+            step_x(s + 1, xb);
             gemv_step_any<Codec, NBG>(lut, laneoff, wb, xb, acc);
         }
     }
