@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include "seq.h"
 #include "tcq_kernels_api.h"
 
 namespace qpal {
@@ -109,8 +110,7 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
         hipFree(d);
     }
 #endif
-    hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(64 * gemv_waves<NBG>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, mp);
-    return (int)hipGetLastError();
+    return launch_gemv_kernel<C1, C2, NBG, ROT>(e, mp, grid, stream);
 }
 
 
