@@ -25,14 +25,13 @@
 extern "C" {
 #endif
 
-#define QPAL_VERSION 310
+#define QPAL_VERSION 300
 
 #define QPAL_OK 0
 #define QPAL_E_SHAPE (-1)   /* m, k, n outside the supported set (m%32, k%32, 1<=n<=128 ...) */
 #define QPAL_E_PARAM (-2)   /* S / KV / bits / vec / split combination not supported        */
 #define QPAL_E_NULL (-3)    /* required pointer is NULL                                      */
 #define QPAL_E_ALIGN (-4)   /* pointer not aligned to the format's natural alignment         */
-#define QPAL_E_SEQ (-5)     /* launch sequence used out of order (begin twice, launch while recording or inside a graph capture) */
 
 /* split modes of the TCQ family (lib/linear/comb_linear.py) */
 #define QPAL_SPLIT_NONE 0   /* QTIPLinearTCQ:  one stream c1 @ KV1                                   */
@@ -302,26 +301,6 @@ int qpal_can_fuse_rotation_k(int n, int k, int K);
  *                           wave-steps executed = grid * 16 * iters (one step = 32 rows x 128 columns of W).            */
 int qpal_calib_stream_read(const void *const *srcs, const long *bytes, int nseg, void *sink, int grid, void *stream);
 int qpal_calib_decode_rate(const void *tlut, void *sink, int iters, int S, int KV, int grid, void *stream);
-
-/* ---- Launch sequences (round 5) -----------------------------------------------------------------------------------------
- * The caller loop this replaces: eval/measure_latency.py:130-135, 236-254 — the reference replays its per-token launches from a CUDA
- * graph.  A sequence is this library's own replayable list: between qpal_seq_begin and qpal_seq_end every launching entry point of
- * this header RECORDS (on the calling thread) instead of launching; qpal_seq_launch re-issues the list on `stream`.  The fused GEMV
- * launches of batch <= 8 whose x is staged in LDS go out WITHOUT the barrier bit of their AQL packet and keep the dependency on the
- * launch before them by in-kernel arrival counters: their workgroups start, fetch arguments, build the codebook image and request
- * their first weights while the previous launch drains, and wait before they read x or write anything.  Everything else in the list
- * is re-issued in plain stream order.  Results are bit-identical to issuing the same calls on the stream.
- * Rules: the buffers named by the recorded calls must stay alive and in place; one replay at a time per sequence (replays on ONE stream
- * serialise by themselves: the first launch of a sequence is stream-ordered); not inside a stream capture (QPAL_E_SEQ: a graph drops
- * the launch flag).  QPAL_SEQ_OVERLAP=0 in the environment at qpal_seq_end: every launch stream-ordered (A/B switch).
- * qpal_seq_info: launches recorded, how many of them start under their predecessor, and — after the caller has synchronised the
- * stream — the sequence's error word (0; else 1 + the workgroup whose bounded wait for its predecessor ran out).               */
-int qpal_seq_create(void **seq);
-int qpal_seq_begin(void *seq);
-int qpal_seq_end(void *seq);
-int qpal_seq_launch(void *seq, void *stream);
-int qpal_seq_info(void *seq, int *launches, int *overlapped, unsigned *err);
-int qpal_seq_destroy(void *seq);
 
 const char *qpal_error_string(int code);
 int qpal_version(void);

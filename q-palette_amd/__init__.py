@@ -10,7 +10,6 @@ Layout:
   hadamard.py      get_hadK (generated Paley factors), matmul_hadU*_cuda, the one-launch `rotate` (lib/utils/matmul_had.py)
   linear/incoherent_linear.py  IncoherentLinear / IncoherentMLP / IncoherentSdpaAttention (lib/linear/incoherent_linear.py)
   packers.py       pack_trellis / pack_qweight / pack_qweight_{sq,vq}_simt on the C-ABI's host-side encoders
-  sequence.py      LaunchSequence: record a token's launches once, replay them with overlapped launch boundaries (csrc/seq.hip)
   shard.py         row-sharding of packed layers across GPUs (torch.distributed / RCCL)
 
 There is deliberately no CPU implementation here: the CPU restatement lives in /oracle and is test
@@ -22,7 +21,6 @@ from . import mem_op  # noqa: F401
 from . import shard  # noqa: F401
 from . import hadamard  # noqa: F401
 from . import packers  # noqa: F401
-from .sequence import LaunchSequence  # noqa: F401
 from .linear import (  # noqa: F401
     IncoherentLinear,
     IncoherentMLP,

@@ -67,12 +67,6 @@ _SIGNATURES = {
     "qpal_ipc_export": [_P, ctypes.c_char_p],
     "qpal_ipc_open": [ctypes.c_char_p, ctypes.POINTER(_P)],
     "qpal_ipc_close": [_P],
-    "qpal_seq_create": [ctypes.POINTER(_P)],
-    "qpal_seq_begin": [_P],
-    "qpal_seq_end": [_P],
-    "qpal_seq_launch": [_P, _P],
-    "qpal_seq_info": [_P, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_uint)],
-    "qpal_seq_destroy": [_P],
     "qpal_calib_stream_read": [ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_long), _I, _P, _I, _P],
     "qpal_calib_decode_rate": [_P, _P, _I, _I, _I, _I, _P],
 }

@@ -8,7 +8,6 @@
 #include <hip/hip_runtime.h>
 
 #include "qpal_common.h"
-#include "seq.h"
 
 namespace qpal {
 
@@ -827,8 +826,6 @@ using namespace qpal;
 
 extern "C" int qpal_attn_decode(const void *q_f16, const void *kcache_f16, const void *vcache_f16, void *out_f16, const long *pos,
                                 int nq, int nkv, int hd, long max_len, float scale, void *stream) {
-    if (qpal::SeqRecorder *r_ = qpal::seq_recording())  // (launch sequences: re-issued in stream order at replay)
-        return qpal::seq_record_call(r_, [=](hipStream_t s_) { return qpal_attn_decode(q_f16, kcache_f16, vcache_f16, out_f16, pos, nq, nkv, hd, max_len, scale, s_); });
     if (!q_f16 || !kcache_f16 || !vcache_f16 || !out_f16 || !pos) return QPAL_E_NULL;
     if (nq < 1 || nkv < 1 || nq % nkv || hd < 8 || hd % 8 || max_len < 1) return QPAL_E_SHAPE;
     const size_t lds = sizeof(float) * ((size_t)max_len + 5 * (size_t)hd + 8);
@@ -851,8 +848,6 @@ extern "C" int qpal_attn_decode(const void *q_f16, const void *kcache_f16, const
 
 extern "C" int qpal_rope_kv(const float *q, const float *k, const float *v, void *q_out_f16, void *kcache_f16, void *vcache_f16,
                             const long *pos, const float *inv_freq, int nq, int nkv, int hd, long max_len, void *stream) {
-    if (qpal::SeqRecorder *r_ = qpal::seq_recording())  // (launch sequences: re-issued in stream order at replay)
-        return qpal::seq_record_call(r_, [=](hipStream_t s_) { return qpal_rope_kv(q, k, v, q_out_f16, kcache_f16, vcache_f16, pos, inv_freq, nq, nkv, hd, max_len, s_); });
     if (!q || !k || !v || !q_out_f16 || !kcache_f16 || !vcache_f16 || !pos || !inv_freq) return QPAL_E_NULL;
     if (nq < 1 || nkv < 1 || hd < 2 || hd % 2 || max_len < 1) return QPAL_E_SHAPE;
     RopeParams p{q, k, v, static_cast<uint16_t *>(q_out_f16), static_cast<uint16_t *>(kcache_f16),
@@ -908,8 +903,6 @@ static int launch_attn(Kern kern, const Params &p, int grid, int threads, size_t
 extern "C" int qpal_attn_rope_decode(const float *q, const float *k, const float *v, void *kcache_f16, void *vcache_f16, void *out_f16,
                                      const long *pos, const float *inv_freq, int nq, int nkv, int hd, long max_len, float scale,
                                      void *ws, long ws_bytes, void *stream) {
-    if (qpal::SeqRecorder *r_ = qpal::seq_recording())  // (launch sequences: re-issued in stream order at replay)
-        return qpal::seq_record_call(r_, [=](hipStream_t s_) { return qpal_attn_rope_decode(q, k, v, kcache_f16, vcache_f16, out_f16, pos, inv_freq, nq, nkv, hd, max_len, scale, ws, ws_bytes, s_); });
     if (!q || !k || !v || !kcache_f16 || !vcache_f16 || !out_f16 || !pos || !inv_freq) return QPAL_E_NULL;
     if (nq < 1 || nkv < 1 || nq % nkv || max_len < 1 || max_len >= (1L << 30) || (hd != 64 && hd != 128 && hd != 256)) return QPAL_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(kcache_f16) | reinterpret_cast<uintptr_t>(vcache_f16)) & 15) return QPAL_E_ALIGN;
@@ -952,8 +945,6 @@ extern "C" long qpal_lm_head_ws_bytes(int vocab) { return vocab > 0 ? (2L * lm_h
 
 extern "C" int qpal_lm_head_argmax(const float *h_f32, const void *rms_w_f16, float rms_eps, const void *w_f16, float *logits_f32,
                                    long *token, void *ws, long ws_bytes, int vocab, int k, void *stream) {
-    if (qpal::SeqRecorder *r_ = qpal::seq_recording())  // (launch sequences: re-issued in stream order at replay)
-        return qpal::seq_record_call(r_, [=](hipStream_t s_) { return qpal_lm_head_argmax(h_f32, rms_w_f16, rms_eps, w_f16, logits_f32, token, ws, ws_bytes, vocab, k, s_); });
     if (!h_f32 || !w_f16 || !token || !ws) return QPAL_E_NULL;
     if (vocab < 1 || (k != 2048 && k != 4096 && k != 8192)) return QPAL_E_SHAPE;
     if (ws_bytes < qpal_lm_head_ws_bytes(vocab)) return QPAL_E_SHAPE;

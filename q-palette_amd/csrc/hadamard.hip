@@ -14,7 +14,6 @@
 //   3. out = fp16( fp16(u) * post_scale [* sv] ).
 #include "qpal_common.h"
 #include "wht64.h"
-#include "seq.h"
 
 namespace qpal {
 
@@ -690,15 +689,11 @@ static int hadamard_impl(void *out_f16, const void *in, const void *su, const vo
 
 extern "C" int qpal_hadamard(void *out_f16, const void *in, const void *su, const void *sv, const void *hadk, int rows,
                              int n, int hd, int K, int in_mode, int round_mid, float post_scale, void *stream) {
-    if (qpal::SeqRecorder *r_ = qpal::seq_recording())  // (launch sequences: re-issued in stream order at replay)
-        return qpal::seq_record_call(r_, [=](hipStream_t s_) { return qpal_hadamard(out_f16, in, su, sv, hadk, rows, n, hd, K, in_mode, round_mid, post_scale, s_); });
     return hadamard_impl(out_f16, in, su, sv, hadk, rows, n, hd, K, in_mode, round_mid, post_scale, 0.f, nullptr, stream);
 }
 
 extern "C" int qpal_hadamard_rms(void *out_f16, const float *in_f32, const void *rms_w, float rms_eps, const void *su, const void *hadk,
                                  int rows, int n, int K, float post_scale, void *stream) {
-    if (qpal::SeqRecorder *r_ = qpal::seq_recording())  // (launch sequences: re-issued in stream order at replay)
-        return qpal::seq_record_call(r_, [=](hipStream_t s_) { return qpal_hadamard_rms(out_f16, in_f32, rms_w, rms_eps, su, hadk, rows, n, K, post_scale, s_); });
     if (!(rms_eps > 0.f)) return QPAL_E_PARAM;
     if (rms_w && (reinterpret_cast<uintptr_t>(rms_w) & 1)) return QPAL_E_ALIGN;
     return hadamard_impl(out_f16, in_f32, su, nullptr, hadk, rows, n, n, K, QPAL_IN_F32, 1, post_scale, rms_eps, rms_w, stream);

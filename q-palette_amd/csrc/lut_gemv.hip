@@ -1,6 +1,5 @@
 // VQ/SQ tensor-core-format fused decode+GEMV kernels (batch 1..8) + launcher.
 #include "lut_kernels_api.h"
-#include "seq.h"
 
 namespace qpal {
 
@@ -10,9 +9,13 @@ int launch_lut_tc_gemv(const TcMultiParams &p, int bits, int vec, int nbg, int g
     const TcEarly e = early_args(p);
 #define QPAL_LUT(B_, V_)                                                                                       \
     if (bits == B_ && vec == V_) {                                                                             \
-        if (nbg == 1) return launch_gemv_kernel<LutCodec<B_, V_>, void, 1, 0>(e, p, grid, stream);              \
-        if (nbg == 2) return launch_gemv_kernel<LutCodec<B_, V_>, void, 2, 0>(e, p, grid, stream);              \
-        return launch_lut_tc_gemv_wide(p, bits, vec, nbg, grid, stream);                                       \
+        if (nbg == 1)                                                                                          \
+            hipLaunchKernelGGL((tc_gemv_kernel<LutCodec<B_, V_>, void, 1>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, p); \
+        else if (nbg == 2)                                                                                     \
+            hipLaunchKernelGGL((tc_gemv_kernel<LutCodec<B_, V_>, void, 2>), dim3(grid), dim3(64 * gemv_waves<2>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, p); \
+        else                                                                                                   \
+            return launch_lut_tc_gemv_wide(p, bits, vec, nbg, grid, stream);                                   \
+        return (int)hipGetLastError();                                                                         \
     }
 #include "lut_table.inc"
 #undef QPAL_LUT

@@ -1,6 +1,5 @@
 // VQ/SQ tensor-core-format GEMV kernels that also apply the incoherence rotation to x while staging it.
 #include "lut_kernels_api.h"
-#include "seq.h"
 
 namespace qpal {
 
@@ -9,7 +8,8 @@ int launch_lut_tc_gemv_rot(const TcMultiParams &p, int bits, int vec, int grid, 
     const TcEarly e = early_args(p);
 #define QPAL_LUT(B_, V_)                                                                                           \
     if (bits == B_ && vec == V_) {                                                                                 \
-        return launch_gemv_kernel<LutCodec<B_, V_>, void, 1, 1>(e, p, grid, stream);                               \
+        hipLaunchKernelGGL((tc_gemv_kernel<LutCodec<B_, V_>, void, 1, 1>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, p); \
+        return (int)hipGetLastError();                                                                             \
     }
 #include "lut_table.inc"
 #undef QPAL_LUT

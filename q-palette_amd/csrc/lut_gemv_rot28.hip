@@ -1,7 +1,6 @@
 // VQ/SQ tensor-core-format GEMV kernels whose x staging applies the 14336-wide rotation of rot_k28.h (codecs whose codebook image
 // can lend it 40 KiB of LDS; the host refuses the others: qpal_capi.hip rot_k28_ok).
 #include "lut_kernels_api.h"
-#include "seq.h"
 
 namespace qpal {
 
@@ -10,7 +9,8 @@ int launch_lut_tc_gemv_rot28(const TcMultiParams &p, int bits, int vec, int grid
 #define QPAL_LUT(B_, V_)                                                                                           \
     if (bits == B_ && vec == V_) {                                                                                 \
         if constexpr (LutCodec<B_, V_>::LDS_DWORDS * 4 >= kP28 * kTbRow) {                                         \
-            return launch_gemv_kernel<LutCodec<B_, V_>, void, 1, 2>(e, p, grid, stream);                           \
+            hipLaunchKernelGGL((tc_gemv_kernel<LutCodec<B_, V_>, void, 1, 2>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, p); \
+            return (int)hipGetLastError();                                                                         \
         } else {                                                                                                   \
             return QPAL_E_SHAPE;                                                                                   \
         }                                                                                                          \

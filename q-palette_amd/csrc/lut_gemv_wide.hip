@@ -1,6 +1,5 @@
 // VQ/SQ (tensor-core packing) fused decode + skinny GEMM for batches 17..64 (512-thread workgroups).
 #include "lut_kernels_api.h"
-#include "seq.h"
 
 namespace qpal {
 
@@ -9,9 +8,9 @@ int launch_lut_tc_gemv_wide(const TcMultiParams &p, int bits, int vec, int nbg, 
 #define QPAL_LUT(B_, V_)                                                                                       \
     if (bits == B_ && vec == V_) {                                                                             \
         if (nbg == 4) {                                                                                        \
-            return launch_gemv_kernel<LutCodec<B_, V_>, void, 4, 0>(e, p, grid, stream);                       \
+            hipLaunchKernelGGL((tc_gemv_kernel<LutCodec<B_, V_>, void, 4>), dim3(grid), dim3(512), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, p); \
         } else if constexpr (LutCodec<B_, V_>::LDS_DWORDS * 4 <= 64 * 1024) {  /* 8 groups: 64 KiB reduction buffer */ \
-            return launch_gemv_kernel<LutCodec<B_, V_>, void, 8, 0>(e, p, grid, stream);                       \
+            hipLaunchKernelGGL((tc_gemv_kernel<LutCodec<B_, V_>, void, 8>), dim3(grid), dim3(512), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, p); \
         } else {                                                                                               \
             return QPAL_E_SHAPE;                                                                               \
         }                                                                                                      \

@@ -7,7 +7,6 @@
 
 #include "lut_kernels_api.h"
 #include "tcq_kernels_api.h"
-#include "seq.h"
 #include "tc_gemm16.h"
 #include <string.h>
 
@@ -575,16 +574,14 @@ int dequant_chunks(int nrows, int st1, int st2) {
 int zero_if_split(const TcParams &p, int m, hipStream_t stream, int out_zeroed = 0) {
     if (p.sk > 1 && !out_zeroed && !p.accumulate) {
         // ONE node for the whole [n][m] block (a batch of 64 used to cost 64 memset nodes per layer)
-        hipError_t e = p.ldo == m ? zero_async(p.out, 0, sizeof(float) * (size_t)m * p.n, 1, stream)
-                                  : zero_async(p.out, sizeof(float) * (size_t)p.ldo, sizeof(float) * (size_t)m, (size_t)p.n, stream);
+        hipError_t e = p.ldo == m ? hipMemsetAsync(p.out, 0, sizeof(float) * (size_t)m * p.n, stream)
+                                  : hipMemset2DAsync(p.out, sizeof(float) * (size_t)p.ldo, 0, sizeof(float) * (size_t)m, (size_t)p.n, stream);
         if (e != hipSuccess) return (int)e;
     }
     return 0;
 }
 
 int launch_tcq_gemm(const TcMultiParams &mp, int S, int KV1, int KV2, int nbg, int grid, hipStream_t stream) {
-    if (SeqRecorder *r = seq_recording())  // (re-issued in stream order)
-        return seq_record_call(r, [=](hipStream_t s) { return launch_tcq_gemm(mp, S, KV1, KV2, nbg, grid, s); });
     return nbg == 1 ? launch_tcq_gemm_nbg1(mp, S, KV1, KV2, grid, stream)
          : nbg == 2 ? launch_tcq_gemm_nbg2(mp, S, KV1, KV2, grid, stream)
          : nbg == 4 ? launch_tcq_gemm_nbg4(mp, S, KV1, KV2, grid, stream)
@@ -617,7 +614,7 @@ int zero_split_jobs(const TcMultiParams &mp, const int *ms, const int *zeroed, h
         size_t bytes = spans[i].bytes;
         int k = i + 1;
         while (k < ns && spans[k].p == p0 + bytes) bytes += spans[k++].bytes;
-        hipError_t e = zero_async(p0, 0, bytes, 1, stream);
+        hipError_t e = hipMemsetAsync(p0, 0, bytes, stream);
         if (e != hipSuccess) return (int)e;
         i = k;
     }
@@ -799,8 +796,6 @@ int qpal_tcq_gemv_multi(const qpal_tcq_job *jobs, int njobs, int n, int S, int K
 
 int qpal_tcq_dequant(void *out_f16, const void *c1, const void *c2, const void *tlut, int m, int k, int S, int KV1,
                      int KV2, int split, void *stream) {
-    if (qpal::SeqRecorder *r_ = qpal::seq_recording())  // (launch sequences: re-issued in stream order at replay)
-        return qpal::seq_record_call(r_, [=](hipStream_t s_) { return qpal_tcq_dequant(out_f16, c1, c2, tlut, m, k, S, KV1, KV2, split, s_); });
     int rc = tcq_check(c1, c2, tlut, m, k, S, KV1, KV2, split);
     if (rc) return rc;
     if (!out_f16) return QPAL_E_NULL;
@@ -938,10 +933,6 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
         plan_gemm(mp, grid, nbg_of(rows) <= env_int("QPAL_GEMM_TWO_NBG", 1) && lut_image_bytes(bits, vec) <= 64 * 1024, nbg_of(rows) >= 4 ? kG16Waves : kGemmWaves);
         int rc = zero_split_jobs(mp, ms, zeroed, s);
         if (rc) return rc;
-        if (SeqRecorder *r = seq_recording()) {  // (re-issued in stream order)
-            const int nbg_r = nbg_of(rows);
-            return seq_record_call(r, [=](hipStream_t s2) { return launch_lut_tc_gemm(mp, bits, vec, nbg_r, grid, s2); });
-        }
         return launch_lut_tc_gemm(mp, bits, vec, nbg_of(rows), grid, s);
     }
     if (nbg > 8) return QPAL_E_SHAPE;  // (batches 65..128: the lockstep kernel only)
@@ -960,8 +951,6 @@ int qpal_lut_tc_gemv_multi(const qpal_lut_job *jobs, int njobs, int n, int bits,
 
 int qpal_lut_tc_dequant(void *out_f16, const void *qweight, const void *lut, int m, int k, int bits, int vec,
                         void *stream) {
-    if (qpal::SeqRecorder *r_ = qpal::seq_recording())  // (launch sequences: re-issued in stream order at replay)
-        return qpal::seq_record_call(r_, [=](hipStream_t s_) { return qpal_lut_tc_dequant(out_f16, qweight, lut, m, k, bits, vec, s_); });
     if (!out_f16 || !qweight || !lut) return QPAL_E_NULL;
     if (m <= 0 || k <= 0 || m % 32 || k % 32) return QPAL_E_SHAPE;
     if (!lut_tc_ok(bits, vec) || ((long)bits * k) % (32 * vec)) return QPAL_E_PARAM;
@@ -983,8 +972,6 @@ int qpal_lut_tc_dequant(void *out_f16, const void *qweight, const void *lut, int
 
 int qpal_lut_simt_gemv(void *out_f16, const void *qweight, const void *x, const void *lut, int m, int n, int k,
                        int bits, int vec, void *stream) {
-    if (qpal::SeqRecorder *r_ = qpal::seq_recording())  // (launch sequences: re-issued in stream order at replay)
-        return qpal::seq_record_call(r_, [=](hipStream_t s_) { return qpal_lut_simt_gemv(out_f16, qweight, x, lut, m, n, k, bits, vec, s_); });
     if (!out_f16 || !qweight || !x || !lut) return QPAL_E_NULL;
     if (m <= 0 || k <= 0 || n < 1 || n > 8 || k % (32 * vec)) return QPAL_E_SHAPE;
     if (!simt_ok(bits, vec)) return QPAL_E_PARAM;
@@ -997,8 +984,6 @@ int qpal_lut_simt_gemv(void *out_f16, const void *qweight, const void *x, const 
 
 int qpal_lut_simt_dequant(void *out_f16, const void *qweight, const void *lut, int m, int k, int bits, int vec,
                           void *stream) {
-    if (qpal::SeqRecorder *r_ = qpal::seq_recording())  // (launch sequences: re-issued in stream order at replay)
-        return qpal::seq_record_call(r_, [=](hipStream_t s_) { return qpal_lut_simt_dequant(out_f16, qweight, lut, m, k, bits, vec, s_); });
     if (!out_f16 || !qweight || !lut) return QPAL_E_NULL;
     if (m <= 0 || k <= 0 || k % (32 * vec)) return QPAL_E_SHAPE;
     if (!simt_ok(bits, vec)) return QPAL_E_PARAM;
@@ -1011,8 +996,6 @@ int qpal_lut_simt_dequant(void *out_f16, const void *qweight, const void *lut, i
 }
 
 int qpal_tc_to_simt(void *dst_simt, const void *src_tc, int m, int k, int bits, int vec, void *stream) {
-    if (qpal::SeqRecorder *r_ = qpal::seq_recording())  // (launch sequences: re-issued in stream order at replay)
-        return qpal::seq_record_call(r_, [=](hipStream_t s_) { return qpal_tc_to_simt(dst_simt, src_tc, m, k, bits, vec, s_); });
     if (!dst_simt || !src_tc) return QPAL_E_NULL;
     if (m <= 0 || k <= 0 || m % 32 || k % 32 || k % (32 * vec)) return QPAL_E_SHAPE;
     if (!(vec == 1 || vec == 2) || !lut_tc_ok(bits, vec) || ((long)bits * k) % (32 * vec)) return QPAL_E_PARAM;
@@ -1094,7 +1077,6 @@ const char *qpal_error_string(int code) {
         case QPAL_E_PARAM: return "unsupported quantizer parameters (S/KV/bits/vec/split)";
         case QPAL_E_NULL: return "null pointer";
         case QPAL_E_ALIGN: return "misaligned pointer";
-        case QPAL_E_SEQ: return "launch sequence used out of order (recording already open / not sealed / launch inside a stream capture)";
         default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "unknown qpal error";
     }
 }

@@ -94,9 +94,6 @@ struct LaunchPlan {
 };
 
 constexpr int kMaxJobs = 8;
-constexpr int kSeqShards = 8;            // arrival counters per launch, one 128-byte line each (ONE counter: 3-7 us per hand-over, profiles/r02_dlo_probe.txt)
-constexpr unsigned kSeqGuard = 1u << 18;  // polls before a wait gives up (~0.3 s)
-constexpr int kSeqWaitBit = 28;          // TcEarly::on: the launch waits for its predecessor's arrival counters (x is NOT requested early)
 
 // Several independent GEMVs (same codec, same batch) run by ONE launch: persistent workgroups walk the
 // concatenated item lists of the jobs.  Cuts the per-launch fixed cost (kernel-argument fetch, codebook
@@ -107,15 +104,6 @@ struct TcMultiParams {
     int total_items;
     int zero_chunks;   // 16-byte chunks of `zero` this launch fills with zeros (0: none)
     u32x4 *zero;       // buffer pre-zeroed for a later split-K launch on the same stream
-    // Launch sequences (qpal_seq_*, round 5): the fused GEMV launches of a recorded sequence go out WITHOUT the barrier bit of their
-    // AQL packet (hipExtAnyOrderLaunch), so the workgroups of launch i + 1 take over the CUs launch i's workgroups leave, fetch their
-    // arguments, build the codebook image and request their first weights while launch i drains — and wait HERE, on the arrival
-    // counters of launch i, before they touch anything a launch may have written (x, the outputs, the zero-fill).
-    const unsigned *seq_wait;  // the predecessor's arrival counters: kSeqShards lines of 32 words (null: stream order holds)
-    unsigned seq_need;         // completions of the predecessor this launch needs: counters only grow, the compare is wrap-safe
-    int seq_wait_grid;         // the predecessor's grid: shard j counts its workgroups with blockIdx % kSeqShards == j
-    unsigned *seq_signal;      // this launch's arrival counters (null: nobody waits for it)
-    unsigned *seq_err;         // error word of the sequence: a bounded wait ran out (the launch then runs on: wrong data, no hang)
     int item_end[kMaxJobs];   // lockstep GEMM kernel (tc_gemm.h): items of jobs 0..j
     // fused GEMV kernel (round 5): table-driven geometry
     int ncls;                 // geometry classes in this launch (1 or 2)
@@ -819,22 +807,6 @@ __device__ __forceinline__ void rot_stage1_regs(const u32x4 (&rq)[2][4], bool f3
     }
 }
 
-#ifndef QPAL_ANY_EARLY
-#define QPAL_ANY_EARLY 1  // round 4: with the early loads outside the compiler's bookkeeping (inline asm) and the first item as its own
-#endif                    // body, the any-KV kernels hold them without spilling (round 3: 16-28 spilled VGPRs, early staging off)
-// Does this instantiation have the early-staging prologue (and with it the sequence wait of a launch that starts under its predecessor)?
-// Host and kernel agree through this one definition.
-template <class C1, int NBG, int ROT>
-constexpr bool gemv_early_kernel_v =
-    NBG == 1 && (ROT == 0 || ROT == 3) && ((C1::CHUNKS + 64 * gemv_waves<NBG>() - 1) / (64 * gemv_waves<NBG>())) * (64 * gemv_waves<NBG>()) <= 4096 &&
-    (QPAL_ANY_EARLY || !is_any_v<C1>);
-
-// agent-scope (write-through / L2-coherent across the XCDs) accesses to what one launch of a sequence hands to the next
-__device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(as_global(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic_store(as_global(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(float *p, float v) { st_agent(reinterpret_cast<unsigned *>(p), __builtin_bit_cast(unsigned, v)); }
-__device__ __forceinline__ float ld_agent(const float *p) { return __builtin_bit_cast(float, ld_agent(reinterpret_cast<const unsigned *>(p))); }
-
 // ROT: 0 plain; 1: can rotate x while staging it (k = 2048 / 4096, wht64.h); 2: the 14336-wide rotation of rot_k28.h (its own
 // instantiation: its registers would make the other rotating launches spill); 3: plain + pair mode (TcParams: sk == -1)
 template <class C1, class C2, int NBG, int ROT = 0>
@@ -870,14 +842,15 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     // 8.3 us (llama3.1-8b_figure1c 651 -> 707 tok/s, mem3p25 678 -> 722, one box: profiles/r03_ab_any_spills.txt).
     constexpr bool kXPerm = QPAL_XPERM_PLAIN != 0 && (ROT == 0 || ROT == 3);  // staged x in the permuted layout (xs_put)
     constexpr int kXL = kXPerm ? 2 : 1;
-    constexpr bool kEarly = gemv_early_kernel_v<C1, NBG, ROT>;
+#ifndef QPAL_ANY_EARLY
+#define QPAL_ANY_EARLY 1  // round 4: with the early loads outside the compiler's bookkeeping (inline asm) and the first item as its own
+#endif                    // body, the any-KV kernels hold them without spilling (round 3: 16-28 spilled VGPRs, early staging off)
+    constexpr bool kEarly = NBG == 1 && (ROT == 0 || ROT == 3) && NV * NT <= 4096 && (QPAL_ANY_EARLY || !is_any_v<C1>);
     constexpr int EV = NV < 4 ? NV : 4;  // image entries a thread holds across the argument fetch; the rest are built after it
     constexpr int XR = kEarlyXChunks;    // 16-byte chunks of x a thread holds likewise
     [[maybe_unused]] u32x4 exr[XR];
     [[maybe_unused]] uint32_t etv[EV][C1::RAWN];
     const bool early = kEarly && (eon & 1) != 0;
-    // sequence launch without the barrier bit (TcMultiParams::seq_wait; host: only with `early`, only the kEarly kernels)
-    [[maybe_unused]] const bool seqw = kEarly && ((eon >> kSeqWaitBit) & 1) != 0;
     // Rotating launches (ROT == 1), early part: wave t < x_rot requests its row tile of the rotation's inputs, the other waves the
     // table entries of the codebook image they will build — all of it at the wave's first instruction from preloaded arguments,
     // from inline asm (see part 2a below).  Everything is in by the time the kernel arguments are (~0.3 us), i.e. BEFORE the
@@ -942,7 +915,6 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         // the kernel-argument fetch below and of the first weight loads behind that — the round trips this block exists to overlap.
         if (early) {
             const int total = en * ek;
-            if (!seqw) {  // (a sequence launch that starts under its predecessor reads x behind its wait: part 2b)
 #pragma unroll
             for (int r = 0; r < XR; r++) {
                 const int i = tid * 8 + r * (NT * 8);
@@ -950,7 +922,6 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                 // overwrites the pad chunk with zeros)
                 const uint32_t off = (uint32_t)(i < total ? i : 0) * 2u;
                 asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(exr[r]) : "v"(off), "s"(ex));
-            }
             }
 #pragma unroll
             for (int r = 0; r < EV; r++) {
@@ -1175,12 +1146,10 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
         if constexpr (kEarly) {
             if (FIRST && early) {  // early staging, part 2b: registers -> LDS
                 const int total = en * ek;
-                if (!seqw) {
 #pragma unroll
                 for (int r = 0; r < XR; r++) {
                     const int i = tid * 8 + r * (NT * 8);
                     if (i < total + 32) xs_put<kXPerm>(xs, i, i < total ? exr[r] : u32x4{0u, 0u, 0u, 0u});
-                }
                 }
 #pragma unroll
                 for (int r = 0; r < EV; r++) {
@@ -1194,44 +1163,6 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                         reinterpret_cast<u32x4 *>(lut)[c] = u32x4{v, v, v, v};
                     }
                 }
-                if (seqw) {
-                    // The launch started while its predecessor was still running: arguments fetched, image built, first weights in
-                    // flight — now wait for the predecessor's workgroups (wave 0 polls the arrival counters, one lane per shard),
-                    // then read x with agent-scope loads (the producer wrote it through; a plain load could hit a line this XCD's L2
-                    // kept from the previous token).
-                    if (wave == 0) {
-                        const unsigned *ctr = mp.seq_wait;
-                        const unsigned done = mp.seq_need;
-                        const int pg = mp.seq_wait_grid;
-                        unsigned need = 0;
-                        if (lane < kSeqShards) need = (unsigned)((pg + kSeqShards - 1 - lane) / kSeqShards) * done;
-                        unsigned guard = 0;
-                        for (;;) {
-                            unsigned seen = need;
-                            if (lane < kSeqShards) seen = ld_agent(ctr + lane * 32);
-                            if (__all((int)(seen - need) >= 0)) break;
-                            __builtin_amdgcn_s_sleep(1);
-                            if (++guard > kSeqGuard) {
-                                if (lane == 0) st_agent(mp.seq_err, 1u + (unsigned)blockIdx.x);
-                                break;
-                            }
-                        }
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int r = 0; r < XR; r++) {
-                        const int i = tid * 8 + r * (NT * 8);
-                        const uint32_t off = (uint32_t)(i < total ? i : 0) * 2u;
-                        asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(exr[r]) : "v"(off), "s"(ex));
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int r = 0; r < XR; r++) {
-                        asm volatile("" : "+v"(exr[r]));
-                        const int i = tid * 8 + r * (NT * 8);
-                        if (i < total + 32) xs_put<kXPerm>(xs, i, i < total ? exr[r] : u32x4{0u, 0u, 0u, 0u});
-                    }
-                }
                 cur_x = ex;
                 cur_tab = etab;
                 QPAL_STAMP(2);  // (staged; stamp 3 is behind the barrier)
@@ -1239,12 +1170,6 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
             }
         }
         if (FIRST && mp.zero_chunks > 0) {  // pre-zero a buffer for a later split-K launch on this stream
-            if (mp.seq_signal) {  // (a launch of a sequence: written through, the consumer may start before this kernel has ended)
-                for (int i = blockIdx.x * NT + tid; i < mp.zero_chunks; i += gridDim.x * NT) {
-                    unsigned *z = reinterpret_cast<unsigned *>(mp.zero + i);
-                    st_agent(z, 0u); st_agent(z + 1, 0u); st_agent(z + 2, 0u); st_agent(z + 3, 0u);
-                }
-            } else
             for (int i = blockIdx.x * NT + tid; i < mp.zero_chunks; i += gridDim.x * NT) mp.zero[i] = u32x4{0u, 0u, 0u, 0u};
         }
         if (p.tab != cur_tab || (x_lds && p.x != cur_x)) {  // workgroup-uniform
@@ -1497,11 +1422,9 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
                 for (int qq = 0; qq < run_waves; qq++) v += fred[(qq * p.n + b) * 32];
                 float *dst = fdst + (long)b * p.ldo;
                 v *= osc;
-                // (agent-scope accesses: written through, so that the next launch of a sequence — which may already be running, waiting
-                // on this launch's arrival counters — reads them from any XCD; the float atomics are agent-scope as they are)
                 if (row_shared) atomicAdd(dst, v);
-                else if (p.accumulate) st_agent(dst, ld_agent(dst) + v);  // the residual add of a decoder block: out is the fp32 residual stream
-                else st_agent(dst, v);
+                else if (p.accumulate) *dst += v;  // the residual add of a decoder block: out is the fp32 residual stream
+                else *dst = v;
             }
         }
         QPAL_STAMP(7);
@@ -1511,12 +1434,6 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     int gitem = blockIdx.x;
     run_item(gitem, std::true_type{});
     for (gitem += gridDim.x; gitem < total_items; gitem += gridDim.x) run_item(gitem, std::false_type{});
-    // Arrival (launch sequences): every wave waits for its own stores, then ONE add per workgroup to the launch's sharded counter.
-    if (unsigned *sig = mp.seq_signal) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(as_global(sig + (blockIdx.x & (kSeqShards - 1)) * 32), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------

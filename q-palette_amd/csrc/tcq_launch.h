@@ -3,7 +3,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include "seq.h"
 #include "tcq_kernels_api.h"
 
 namespace qpal {
@@ -110,7 +109,8 @@ static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
         hipFree(d);
     }
 #endif
-    return launch_gemv_kernel<C1, C2, NBG, ROT>(e, mp, grid, stream);
+    hipLaunchKernelGGL((tc_gemv_kernel<C1, C2, NBG, ROT>), dim3(grid), dim3(64 * gemv_waves<NBG>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, mp);
+    return (int)hipGetLastError();
 }
 
 
