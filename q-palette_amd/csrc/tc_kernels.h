@@ -170,7 +170,8 @@ struct TcqCodec {
     // group share a copy, so half of the gathers are 2-way bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.42).  Neither
     // pipe has slack any more: with the pipelined step the VALU and the LDS are each ~73 % busy (545 VALU and 525 LDS
     // cycles of the ~740 a wave-step takes) — the conflict-free 32-copy image (XS = 1) trades a fourth VALU op per pair for them and
-    // measured -12 % when the VALU was the scarcer pipe (round 3); not re-measured since.
+    // measured -12 % in round 3 and -18 % with round 5's pipelined step (profiles/r05_ab_conflict_free_image.txt): the steps phase is
+    // vector-issue bound at ~80 %, the conflicts overlap it.
     static constexpr int XS = XS_;
     static constexpr int ROWSHIFT = 15 - S + XS;       // log2(bytes per entry row)
     static constexpr int LOG2C = ROWSHIFT - 2;         // copies per entry
