@@ -6,7 +6,7 @@ namespace qpal {
 int launch_lut_tc_gemv(const TcMultiParams &p, int bits, int vec, int nbg, int grid, hipStream_t stream) {
     for (int j = 0; j < p.njobs; j++)
         if (p.job[j].x_rot) return nbg == 1 ? launch_lut_tc_gemv_rot(p, bits, vec, grid, stream) : QPAL_E_SHAPE;
-    const TcEarly e = early_args(p);
+    const TcEarly e = early_args(p, grid);
 #define QPAL_LUT(B_, V_)                                                                                       \
     if (bits == B_ && vec == V_) {                                                                             \
         if (nbg == 1)                                                                                          \

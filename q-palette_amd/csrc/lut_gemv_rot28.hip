@@ -5,7 +5,7 @@
 namespace qpal {
 
 int launch_lut_tc_gemv_rot28(const TcMultiParams &p, int bits, int vec, int grid, hipStream_t stream) {
-    const TcEarly e = early_args(p);
+    const TcEarly e = early_args(p, grid);
 #define QPAL_LUT(B_, V_)                                                                                           \
     if (bits == B_ && vec == V_) {                                                                                 \
         if constexpr (LutCodec<B_, V_>::LDS_DWORDS * 4 >= kP28 * kTbRow) {                                         \

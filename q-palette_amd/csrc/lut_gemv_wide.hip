@@ -4,7 +4,7 @@
 namespace qpal {
 
 int launch_lut_tc_gemv_wide(const TcMultiParams &p, int bits, int vec, int nbg, int grid, hipStream_t stream) {
-    const TcEarly e = early_args(p);
+    const TcEarly e = early_args(p, grid);
 #define QPAL_LUT(B_, V_)                                                                                       \
     if (bits == B_ && vec == V_) {                                                                             \
         if (nbg == 4) {                                                                                        \

@@ -736,7 +736,7 @@ struct TcEarly {
 };
 
 // host: the launch qualifies when x is staged in LDS and every job has the same x, codebook and batch
-inline TcEarly early_args(const TcMultiParams &mp) {
+inline TcEarly early_args(const TcMultiParams &mp, int grid) {
     const TcParams &a = mp.job[0];
     // (x and its 32-half zero pad must fit the chunks the threads hold)
     TcEarly e{a.x, a.tab, a.n, a.k, a.x_lds && !a.x_rot && a.n <= 8 && a.n * a.k + 32 <= kEarlyXChunks * 64 * gemv_waves<1>() * 8 ? 1 : 0,
@@ -761,6 +761,10 @@ inline TcEarly early_args(const TcMultiParams &mp) {
         for (int j = 0; j < 3; j++) e.ie |= (j < mp.njobs - 1 ? mp.row_end[j] : 0x3ff) << (10 * j);
         e.on |= (mp.plan[0].lg_g << 16) | (mp.plan[0].rg << 18);
     }
+    // bit 30: ONE round — every workgroup has exactly one item (grid == total_items, the usual case).  The kernel then neither reads
+    // gridDim.x (a hidden kernel argument: one more scalar-load round trip behind the last barrier of EVERY workgroup) nor waits at
+    // the barrier that only protects the reduction buffer against a next item.
+    if (grid >= mp.total_items) e.on |= 1 << 30;
     return e;
 }
 
@@ -956,6 +960,7 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
     // Everything on the way to the first weight loads is in this one batch (round 4: a second, dependent round trip there cost
     // 0.3-0.4 us per launch).
     const bool fast = eie != 0;
+    const bool one_round = ((eon >> 30) & 1) != 0;  // (early_args: grid == total_items — no second item, no look at gridDim.x)
     const int total_items = mp.total_items;  // (requested with the first batch: read behind the first item, it is a whole scalar-load round trip in every workgroup's tail)
     struct Where {  // a wave's place in the launch
         WaveEnt ent;
@@ -1429,12 +1434,13 @@ __global__ QPAL_GEMV_BOUNDS(NBG) void tc_gemv_kernel(const uint16_t *ex, const v
             }
         }
         QPAL_STAMP(7);
-        __syncthreads();
+        if (!one_round) __syncthreads();  // (the next item reuses `red`)
     };
     // (the grid never exceeds the item count: host, plan_launch)
     int gitem = blockIdx.x;
     run_item(gitem, std::true_type{});
-    for (gitem += gridDim.x; gitem < total_items; gitem += gridDim.x) run_item(gitem, std::false_type{});
+    if (!one_round)
+        for (gitem += gridDim.x; gitem < total_items; gitem += gridDim.x) run_item(gitem, std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -5,7 +5,7 @@
 namespace qpal {
 
 int launch_tcq_gemv_any(const TcMultiParams &p, int S, int grid, hipStream_t stream) {
-    const TcEarly e = early_args(p);
+    const TcEarly e = early_args(p, grid);
     if (S == 9) hipLaunchKernelGGL((tc_gemv_kernel<TcqAny<9>, void, 1, false>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, p);
     else if (S == 10) hipLaunchKernelGGL((tc_gemv_kernel<TcqAny<10>, void, 1, false>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, p);
     else if (S == 11) hipLaunchKernelGGL((tc_gemv_kernel<TcqAny<11>, void, 1, false>), dim3(grid), dim3(64 * gemv_waves<1>()), 0, stream, e.x, e.tab, e.n, e.k, e.on, e.ie, e.su, e.rw, p);

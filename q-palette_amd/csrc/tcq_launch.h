@@ -10,7 +10,7 @@ namespace qpal {
 template <int S, int KV1, int KV2, int NBG, int ROT = 0>
 static int launch_one(const TcMultiParams &mp, int grid, hipStream_t stream) {
     [[maybe_unused]] const TcParams &p = mp.job[0];
-    const TcEarly e = early_args(mp);
+    const TcEarly e = early_args(mp, grid);
 #ifndef QPAL_TCQ_XS  // (experiment: 1 = the conflict-free 32-copy codebook image, 128 KiB, for the 1024-entry codebooks)
 #define QPAL_TCQ_XS 0
 #endif
