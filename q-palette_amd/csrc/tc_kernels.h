@@ -489,6 +489,14 @@ __device__ __forceinline__ int xs_index(int i) {
     else return i;
 }
 
+// The MFMA's 16 columns are 8 batch rows x 2 column halves; at batch n < 8 the columns of the batch rows that do not exist used to
+// carry COPIES of row n - 1 (results never stored).  The matrix pipe multiplies whatever it is given: with zeros in those columns
+// (the staged x's zero pad, one broadcast LDS read) its switching power goes down — measured with perf/power_probe.hip: the 8 matrix
+// instructions of a step are ~200 W of the ~1 100 W the decode draws, and the token runs into the card's power limit (shader clock 2.15
+// instead of 2.4 GHz while tokens replay back to back, profiles/r05_power_and_clock.txt).
+#ifndef QPAL_ZERO_B
+#define QPAL_ZERO_B 1
+#endif
 // MFMA B operand of a step.  Lane (kb = lane>>4, c = lane&15) supplies, for batch row b = 8*grp + (c>>1) and
 // column half u = c&1, the 8 activations  x[b][col0 + 32*sc + 16*ksub + 8*jh + 4*u + 0..3], jh = 0,1
 // (order matches the A fragment: jh-major, then the reference lanes A|B, then the element of the pair).
@@ -507,14 +515,15 @@ __device__ __forceinline__ void load_step_x(const StreamView &sv, const uint16_t
         int b = 8 * grp + (c >> 1);
         b = b < n ? b : n - 1;
         const int off = b * k + sv.col0 + sc * 32 + 4 * (c & 1);
+        [[maybe_unused]] const bool real = QPAL_ZERO_B == 0 || 8 * grp + (c >> 1) < n;  // (see QPAL_ZERO_B)
         if constexpr (XLDS == 2) {
             // staged x is PERMUTED inside every 32-half block (xs_put<true>): the four 8-byte pieces a lane needs are
             // contiguous, so the B operand of a step is two ds_read_b128 (4 LDS cycles each) instead of two ds_read2_b64 (8)
-            const uint16_t *row = xs + (live ? off + 12 * (c & 1) : zero_off);
+            const uint16_t *row = xs + (live && real ? off + 12 * (c & 1) : zero_off);
             xb[grp][0] = *reinterpret_cast<const u32x4 *>(row);
             xb[grp][1] = *reinterpret_cast<const u32x4 *>(row + 8);
         } else if constexpr (XLDS == 1) {
-            const uint16_t *row = xs + (live ? off : zero_off);
+            const uint16_t *row = xs + (live && real ? off : zero_off);
 #pragma unroll
             for (int ksub = 0; ksub < 2; ksub++) {
                 const u32x2 lo = *reinterpret_cast<const u32x2 *>(row + 16 * ksub);
@@ -588,15 +597,23 @@ __device__ __forceinline__ void gemv_step_pipe(const uint32_t *lut, uint32_t lan
         constexpr int g = decltype(gc)::value;
         constexpr int ksub = g >> 1, msub = g & 1;
         uint32_t d[8];
+#ifdef QPAL_KO_GATHER  // power / timing experiments (perf/power_probe.hip): the address instead of the gathered entry
+        static_for<0, 8>([&](auto ic) { d[decltype(ic)::value] = ac[decltype(ic)::value]; });
+#else
         static_for<0, 8>([&](auto ic) { d[decltype(ic)::value] = *reinterpret_cast<const uint32_t *>(l8 + ac[decltype(ic)::value]); });
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (g < 3) addrs(std::integral_constant<int, g + 1>{}, an);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef QPAL_KO_MFMA  // (the decoded pairs consumed by nothing: no matrix instruction, no other instruction in their place)
+        asm volatile("" ::"v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(xb[0][ksub]));
+#else
         // fragment order (jh, isB): i = jl + 2*jh + 4*isB
         acc.v[0][msub * 2 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, u32x4{d[0], d[4], d[2], d[6]}),
                                                                         __builtin_bit_cast(half8_t, xb[0][ksub]), acc.v[0][msub * 2 + 0], 0, 0, 0);
         acc.v[0][msub * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, u32x4{d[1], d[5], d[3], d[7]}),
                                                                         __builtin_bit_cast(half8_t, xb[0][ksub]), acc.v[0][msub * 2 + 1], 0, 0, 0);
+#endif
         if constexpr (g < 3) static_for<0, 8>([&](auto ic) { ac[decltype(ic)::value] = an[decltype(ic)::value]; });
     });
 }
@@ -634,6 +651,7 @@ __device__ __forceinline__ void gemv_run(uint32_t (&w)[Codec::NW], const uint32_
         xl = reinterpret_cast<const char *>(xs) + (b * k + sv.col0 + (lane >> 4) * 32 + 16 * (c & 1)) * 2;
         xz = reinterpret_cast<const char *>(xs) + zero_off * 2;
         dead = (sv.nsc - (lane >> 4) + 3) >> 2;  // first step whose supertile column 4 s + (lane >> 4) is >= nsc
+        if (QPAL_ZERO_B != 0 && (c >> 1) >= n) dead = 0;  // a batch row that does not exist: zeros from the first step on (see QPAL_ZERO_B)
     }
     auto step_x = [&](int s, u32x4(&xb)[NBG][2]) {
         if constexpr (XLDS == 2 && NBG == 1) {
