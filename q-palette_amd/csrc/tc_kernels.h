@@ -605,7 +605,18 @@ __device__ __forceinline__ void gemv_step_pipe(const uint32_t *lut, uint32_t lan
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (g < 3) addrs(std::integral_constant<int, g + 1>{}, an);
         __builtin_amdgcn_sched_barrier(0);
-#ifdef QPAL_KO_MFMA  // (the decoded pairs consumed by nothing: no matrix instruction, no other instruction in their place)
+#ifdef QPAL_PROBE_MFMA444  // power / timing probe only (perf/power_probe.hip; the results are NOT the GEMV's): the step's MACs as 16 x 4x4x4
+        {                      // (16 blocks) matrix instructions — a quarter of the products of the 16 x 16 x 32 shape, twice the instructions
+            typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+            typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+            const u32x4 xq = xb[0][ksub];
+            const half4_t b0 = __builtin_bit_cast(half4_t, u32x2_t{xq.x, xq.y}), b1 = __builtin_bit_cast(half4_t, u32x2_t{xq.z, xq.w});
+            acc.v[0][msub * 2 + 0] = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(half4_t, u32x2_t{d[0], d[4]}), b0, acc.v[0][msub * 2 + 0], 0, 0, 0);
+            acc.v[0][msub * 2 + 0] = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(half4_t, u32x2_t{d[2], d[6]}), b1, acc.v[0][msub * 2 + 0], 0, 0, 0);
+            acc.v[0][msub * 2 + 1] = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(half4_t, u32x2_t{d[1], d[5]}), b0, acc.v[0][msub * 2 + 1], 0, 0, 0);
+            acc.v[0][msub * 2 + 1] = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(half4_t, u32x2_t{d[3], d[7]}), b1, acc.v[0][msub * 2 + 1], 0, 0, 0);
+        }
+#elif defined(QPAL_KO_MFMA)  // (the decoded pairs consumed by nothing: no matrix instruction, no other instruction in their place)
         asm volatile("" ::"v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(xb[0][ksub]));
 #else
         // fragment order (jh, isB): i = jl + 2*jh + 4*isB
