@@ -83,7 +83,11 @@ int main(int argc, char **argv) {
     const size_t big_bytes = (size_t)2 << 30; u32x4 *big; hipMalloc(&big, big_bytes); hipMemset(big, 1, big_bytes);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const char *variant =
-#if defined(QPAL_PROBE_MFMA444)
+#if defined(QPAL_KO_HASH)
+        "no hash multiply (v_add in its place)";
+#elif defined(QPAL_HASH_PK16)
+        "hash as v_pk_mad_u16";
+#elif defined(QPAL_PROBE_MFMA444)
         "MACs as 16 x 4x4x4 matrix instructions (probe: a quarter of the products)";
 #elif defined(QPAL_KO_MFMA) && defined(QPAL_KO_GATHER)
         "address arithmetic only (no gathers, no matrix instructions)";

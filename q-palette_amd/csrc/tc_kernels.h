@@ -272,7 +272,13 @@ struct TcqCodec {
     static __device__ __forceinline__ uint32_t addr(uint32_t laneoff, const uint32_t (&w)[NW], uint32_t next_head) {
         const uint32_t s = window<G, I>(w, next_head);
         uint32_t h;
+#if defined(QPAL_KO_HASH)  // power experiment: no multiplier at all (results meaningless)
+        asm("v_add_u32 %0, %1, %1" : "=v"(h) : "v"(s));
+#elif defined(QPAL_HASH_PK16)  // power experiment (perf/power_probe.hip): two 16 x 16 multipliers instead of one 24 x 24 — the low half is the hash
+        asm("v_pk_mad_u16 %0, %1, %1, %1" : "=v"(h) : "v"(s));
+#else
         asm("v_mad_u32_u24 %0, %1, %1, %1" : "=v"(h) : "v"(s));  // s*s + s: low 16 bits exact
+#endif
         if constexpr (XS == 1) asm("v_add_u32 %0, %1, %1" : "=v"(h) : "v"(h));  // (h << 1 as a shift is a half-rate op)
         return (h & HMASK) | laneoff;
     }
